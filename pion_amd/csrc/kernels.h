@@ -1,0 +1,113 @@
+// kernels.h -- launch interface between the C-ABI layer (pion_gpu.hip) and the
+// floating-point kernels (kernels_fp.hip).  kernels_fp.hip is compiled twice,
+// once per floating-point mode, into namespaces pion::fp_strict (-ffp-contract=off:
+// bit-parity with the reference's x86-64 -O3 build) and pion::fp_fast (FMA
+// contraction allowed); pion_gpu_config::strict_fp selects at run time.
+#ifndef PION_KERNELS_H
+#define PION_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_riemann.h"
+
+namespace pion {
+
+#define PION_MAX_NTR 2
+#define PION_COOL_NT_MAX 256
+
+struct GridDesc {
+  int ndim;
+  int ng[3], nbc[3], nga[3];
+  long ncell;   // cells incl. ghosts
+  long sy, sz;  // strides of y and z in cells
+  double dx;
+  double xmin[3];
+};
+
+struct CoolDev {
+  int NT;
+  const double *T;       // [NT]
+  const double *tab;     // [5][NT]  rrhp, C_rrh, C_ffhe, C_fbdn, C_cie
+  const double *slope;   // [5][NT]
+  double inv_Mu2, inv_Mu2_elec_H, Mu_tot_over_kB;
+  double MinT_allowed, MaxT_allowed;
+};
+
+struct StageArgs {
+  GridDesc g;
+  const double *S;    // stencil state ("Ph")      [nvar][ncell]
+  const double *Pc;   // start-of-step state ("P") [nvar][ncell]
+  double *out;        // destination                [nvar][ncell]
+  const uint8_t *flags;
+  const uint8_t *hllflag;   // HLLD->HLL switch per cell (may be null)
+  const double *eta;        // H-correction [ndim][ncell] (may be null)
+  int *errword;
+  FluxCtx fc;
+  int eqntype, ntracer, solver;
+  int space_ooa;
+  int cooling;        // EP.cooling
+  double dt;          // stage dt (= FV_dt)
+  double glm_damp;    // exp(-FV_dt*chyp*cr), evaluated on the host
+  double max_temp;    // EP.MaxTemperature
+  CoolDev cool;
+};
+
+struct PrepassArgs {
+  GridDesc g;
+  const double *S;
+  uint8_t *hllflag;
+  double *divv, *gradp;   // optional debug outputs (null in production)
+  double *eta;            // [ndim][ncell]
+  int eqntype, nvar, space_ooa;
+  double gamma;
+};
+
+struct DtArgs {
+  GridDesc g;
+  const double *P;
+  const double *Ph;
+  const uint8_t *flags;
+  unsigned long long *result;  // [0]=t_dyn bits, [1]=t_mp bits (min over positive doubles)
+  int *errword;
+  int eqntype, nvar;
+  double gamma, cfl;
+  int do_mp;
+  CoolDev cool;
+};
+
+struct FluxTestArgs {
+  int n, axis, eqntype, ntracer, solver;
+  const double *Pl, *Pr, *aux;
+  double *F, *Pstar;
+  int *errword;
+  FluxCtx fc;
+};
+
+struct CoolTestArgs {
+  int n, nvar;
+  double dt, gamma;
+  const double *Pin;
+  double *Pout;
+  const double *rho, *T;
+  double *edot;
+  int *errword;
+  CoolDev cool;
+};
+
+#define PION_DECLARE_FP(NS)                                        \
+  namespace NS {                                                   \
+  int launch_stage(const StageArgs &a, hipStream_t s);             \
+  int launch_prepass(const PrepassArgs &a, hipStream_t s);         \
+  int launch_dt(const DtArgs &a, hipStream_t s);                   \
+  int launch_flux_test(const FluxTestArgs &a, hipStream_t s);      \
+  int launch_cool_update(const CoolTestArgs &a, hipStream_t s);    \
+  int launch_cool_edot(const CoolTestArgs &a, hipStream_t s);      \
+  const char *stage_kernel_name(int eq, int ntr, int solver);      \
+  }
+
+PION_DECLARE_FP(fp_strict)
+PION_DECLARE_FP(fp_fast)
+
+}  // namespace pion
+#endif

@@ -1,0 +1,657 @@
+// kernels_fp.hip -- the floating-point kernels of the flux-update path for gfx950.
+//
+// Compiled twice (Makefile): -DPION_FPNS=fp_strict -ffp-contract=off and
+// -DPION_FPNS=fp_fast -ffp-contract=fast, and per equation set (-DPION_EQSEL).
+//
+//   k_stage    one fused stage of the time integrator for every on-grid cell:
+//              cooling source (time_integrator.cpp:438-489), the directionally-unsplit sweeps
+//              (set_dynamics_dU/dynamics_dU_column, time_integrator.cpp:553-873) and the
+//              state update (grid_update_state_vector + CellAdvanceTime, :881-958).
+//              The reference accumulates cell->dU in memory sweep by sweep; here one
+//              thread owns one cell, rebuilds the two interface fluxes of each axis from
+//              a 5-point stencil per axis, and applies the contributions to its dU in
+//              registers in exactly the reference's order (x,y,z; per axis: Powell/GLM term
+//              of the lower interface, of the upper interface, then the flux difference).
+//              HBM sees: read the stencil state (cached re-reads), read the start-of-step
+//              state, write the new state.
+//   k_prepass  div v / |grad p|/p HLL switch (solver_eqn_base.cpp:398-412) and H-correction
+//              eta (calc_Hcorrection :423-570).
+//   k_dt       CellTimeStep + cooling-time reduction (calc_timestep.cpp:271-507).
+#include "dev_cooling.h"
+#include "kernels.h"
+
+#ifndef PION_FPNS
+#error "PION_FPNS must be defined (fp_strict or fp_fast)"
+#endif
+#ifndef PION_EQSEL
+#define PION_EQSEL 0  // 0 = shared kernels (prepass, dt, cooling tests); 1,2,3 = stage kernels per eqn
+#endif
+
+namespace pion {
+namespace PION_FPNS {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+// SoA variable of sweep-frame slot s for a sweep along ax (run-time version of gvar<>)
+PDEV int rotvar(const int ax, const int s)
+{
+  if (s >= 2 && s <= 4) {
+    int k = (s - 2) + ax;
+    return 2 + (k >= 3 ? k - 3 : k);
+  }
+  if (s >= 5 && s <= 7) {
+    int k = (s - 5) + ax;
+    return 5 + (k >= 3 ? k - 3 : k);
+  }
+  return s;
+}
+// BaseVectorOps::AvgFalle with AVG_MINMOD (coord_sys/VectorOps.cpp:37-59)
+PDEV double avg_falle(const double a, const double b)
+{
+  if (a * b <= PION_VERY_TINY_VALUE) return 0.0;
+  double r = a / b;
+  return (r > 0.0) ? dmin(r, 1.0) * b : 0.0;
+}
+// XCD-aware tile decode: workgroups are dealt round-robin to the 8 XCDs (b % 8 share an XCD);
+// give each XCD a contiguous range of tiles so that the halo re-reads of neighbouring tiles hit
+// the same L2.  Placement only changes speed, never results.
+PDEV long xcd_tile(const long b, const long ntiles)
+{
+  const long chunk = (ntiles + 7) / 8;
+  return (b % 8) * chunk + (b / 8);
+}
+
+// rotate the three vector components between the lab frame and the sweep frame
+template <int NV, bool MHD>
+PDEV void to_sweep(const int ax, const double *lab, double *sw)
+{
+#pragma unroll
+  for (int v = 0; v < NV; v++) sw[v] = lab[v];
+  if (ax == 1) {
+    sw[2] = lab[3]; sw[3] = lab[4]; sw[4] = lab[2];
+    if constexpr (MHD) { sw[5] = lab[6]; sw[6] = lab[7]; sw[7] = lab[5]; }
+  }
+  else if (ax == 2) {
+    sw[2] = lab[4]; sw[3] = lab[2]; sw[4] = lab[3];
+    if constexpr (MHD) { sw[5] = lab[7]; sw[6] = lab[5]; sw[7] = lab[6]; }
+  }
+}
+template <int NV, bool MHD>
+PDEV void from_sweep(const int ax, const double *sw, double *lab)
+{
+#pragma unroll
+  for (int v = 0; v < NV; v++) lab[v] = sw[v];
+  if (ax == 1) {
+    lab[3] = sw[2]; lab[4] = sw[3]; lab[2] = sw[4];
+    if constexpr (MHD) { lab[6] = sw[5]; lab[7] = sw[6]; lab[5] = sw[7]; }
+  }
+  else if (ax == 2) {
+    lab[4] = sw[2]; lab[2] = sw[3]; lab[3] = sw[4];
+    if constexpr (MHD) { lab[7] = sw[5]; lab[5] = sw[6]; lab[6] = sw[7]; }
+  }
+}
+
+#if PION_EQSEL != 0
+// ---------------------------------------------------------------------------
+// select_Hcorr_eta (solver_eqn_base.cpp:608-678) for the interface (cl | cl+st) along ax.
+// The "negative direction" look-ups step back along the SWEEP axis (negdir = 2*axis, :661),
+// as in the reference.
+// ---------------------------------------------------------------------------
+PDEV double select_hcorr_eta(const StageArgs &a, const int ax, const long cl, const long st)
+{
+  const long nc = a.g.ncell;
+  const long cr = cl + st;
+  const int nd = a.g.ndim;
+  double eta = a.eta[ax * nc + cl];
+  if (nd == 1) return eta;
+  int perp = (ax + 1) % nd;
+  eta = dmax(eta, a.eta[perp * nc + cl]);
+  eta = dmax(eta, a.eta[perp * nc + cr]);
+  if (nd > 2) {
+    perp = (ax + 2) % nd;
+    eta = dmax(eta, a.eta[perp * nc + cl]);
+    eta = dmax(eta, a.eta[perp * nc + cr]);
+  }
+  for (int idim = 1; idim < nd; idim++) {
+    perp = (ax + idim) % nd;
+    // cl-st and cr-st exist for every interface an on-grid cell needs (nbc >= 2)
+    eta = dmax(eta, a.eta[perp * nc + (cl - st)]);
+    eta = dmax(eta, a.eta[perp * nc + (cr - st)]);
+  }
+  return eta;
+}
+
+// ---------------------------------------------------------------------------
+// the fused stage kernel
+// ---------------------------------------------------------------------------
+template <int EQ, int NTR, int SOLVER>
+__global__ __launch_bounds__(256) void k_stage(const StageArgs a)
+{
+  typedef Eqn<EQ, NTR> E;
+  typedef Flux<EQ, NTR, SOLVER> FX;
+  constexpr int NV = E::NV;
+  constexpr int BASE = E::BASE;
+  constexpr bool MHD = E::MHD;
+
+  // ---- which cell -------------------------------------------------------
+  const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
+  const long ntiles = (long)nbx * nby * a.g.ng[2];
+  const long tile = xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  const int bx = (int)(tile % nbx), by = (int)((tile / nbx) % nby), bz = (int)(tile / ((long)nbx * nby));
+  const int ix = bx * 64 + (threadIdx.x & 63), iy = by * 4 + (threadIdx.x >> 6), iz = bz;
+  if (ix >= a.g.ng[0] || iy >= a.g.ng[1]) return;
+  const long nc = a.g.ncell;
+  const long c = (long)(ix + a.g.nbc[0]) + a.g.sy * (iy + a.g.nbc[1]) + a.g.sz * (iz + a.g.nbc[2]);
+  const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
+  int err = 0;
+
+  // start-of-step state of this cell (lab frame)
+  double P0[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
+
+  const uint8_t fl = a.flags[c];
+  if (!(fl & 4 /*ISDOMAIN*/) || !(fl & 16 /*ISLEAF*/)) {
+    // grid_update_state_vector skips the cell (time_integrator.cpp:905-908): Ph keeps its value
+#pragma unroll
+    for (int v = 0; v < NV; v++) a.out[v * nc + c] = P0[v];
+    return;
+  }
+
+  double dU[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) dU[v] = 0.0;
+
+  // ---- microphysics source (calc_noRT_microphysics_dU) --------------------
+  if (a.cooling != 0) {
+    const double pg_new = Cooling::time_update(a.cool, P0[qRO], P0[qPG], dt, g, err);
+    double pn[NV], ui[NV], uf[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) pn[v] = P0[v];
+    pn[qPG] = pg_new;
+    E::PtoU(P0, ui, g);
+    E::PtoU(pn, uf, g);
+#pragma unroll
+    for (int v = 0; v < NV; v++) dU[v] += uf[v] - ui[v];
+  }
+
+  // ---- sweeps -------------------------------------------------------------
+  const bool oa2 = (a.space_ooa == 2);
+#pragma unroll 1
+  for (int ax = 0; ax < a.g.ndim; ax++) {
+    const long st = (ax == 0) ? 1 : ((ax == 1) ? a.g.sy : a.g.sz);
+    double qm1[NV], q0[NV], qp1[NV], sm1[NV], s0[NV], sp1[NV];
+    {
+      double qm2[NV], qp2[NV];
+#pragma unroll
+      for (int s = 0; s < NV; s++) {
+        const double *b = a.S + (long)rotvar(ax, s) * nc + c;
+        qm1[s] = b[-st];
+        q0[s] = b[0];
+        qp1[s] = b[st];
+        if (oa2) {
+          qm2[s] = b[-2 * st];
+          qp2[s] = b[2 * st];
+        }
+        else {
+          qm2[s] = qp2[s] = 0.0;
+        }
+      }
+      // SetSlope (VectorOps.cpp:578-617)
+#pragma unroll
+      for (int s = 0; s < NV; s++) {
+        if (oa2) {
+          sm1[s] = avg_falle((qm1[s] - qm2[s]) / dx, (q0[s] - qm1[s]) / dx);
+          s0[s] = avg_falle((q0[s] - qm1[s]) / dx, (qp1[s] - q0[s]) / dx);
+          sp1[s] = avg_falle((qp1[s] - q0[s]) / dx, (qp2[s] - qp1[s]) / dx);
+        }
+        else {
+          sm1[s] = s0[s] = sp1[s] = 0.0;
+        }
+      }
+    }
+    // two interfaces: face 0 = (c-st | c), face 1 = (c | c+st)
+    double Fm[NV], Fp[NV];
+#pragma unroll 1
+    for (int face = 0; face < 2; face++) {
+      double eL[NV], eR[NV], f[NV], pstar[NV];
+      // SetEdgeState (VectorOps.cpp:535-571)
+#pragma unroll
+      for (int s = 0; s < NV; s++) {
+        const double ql = face ? q0[s] : qm1[s], sl = face ? s0[s] : sm1[s];
+        const double qr = face ? qp1[s] : q0[s], sr = face ? sp1[s] : s0[s];
+        if (oa2) {
+          eL[s] = ql + sl * dx * 0.5;
+          eR[s] = qr - sr * dx * 0.5;
+        }
+        else {
+          eL[s] = ql;
+          eR[s] = qr;
+        }
+      }
+      const long cl = face ? c : c - st;
+      double hc_eta = 0.0;
+      if (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98) hc_eta = select_hcorr_eta(a, ax, cl, st);
+      bool use_hll = false;
+      if constexpr (MHD && SOLVER == FLUX_RS_HLLD) use_hll = (a.hllflag[cl] | a.hllflag[cl + st]) != 0;
+      FX::intercell_flux(eL, eR, f, pstar, a.fc, hc_eta, use_hll, err);
+#pragma unroll
+      for (int s = 0; s < NV; s++) {
+        if (face == 0) Fm[s] = f[s];
+        else Fp[s] = f[s];
+      }
+    }
+    // accumulate in the sweep frame, in the reference's order
+    double d[NV];
+    to_sweep<NV, MHD>(ax, dU, d);
+    if constexpr (MHD) {
+      // MHDsource (solver_eqn_mhd_adi.cpp:396-443, GLM :782-813): this cell is the right cell
+      // of face 0 and the left cell of face 1
+      const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
+      const double bm0 = 0.5 * (qm1[qBN] + q0[qBN]);
+      d[uMN] += dt * bm0 * (q0[qBN]) / dx;
+      d[uMT1] += dt * bm0 * (q0[qBT1]) / dx;
+      d[uMT2] += dt * bm0 * (q0[qBT2]) / dx;
+      d[uERG] += dt * bm0 * (uB) / dx;
+      d[uBN] += dt * bm0 * (q0[qVN]) / dx;
+      d[uBT1] += dt * bm0 * (q0[qVT1]) / dx;
+      d[uBT2] += dt * bm0 * (q0[qVT2]) / dx;
+      if constexpr (EQ == EQGLM) {
+        const double sm0 = 0.5 * (qm1[qSI] + q0[qSI]);
+        d[uERG] += dt * sm0 * (q0[qVN] * q0[qSI]) / dx;
+        d[uPSI] += dt * sm0 * q0[qVN] / dx;
+      }
+      const double bm1 = 0.5 * (q0[qBN] + qp1[qBN]);
+      d[uMN] -= dt * bm1 * (q0[qBN]) / dx;
+      d[uMT1] -= dt * bm1 * (q0[qBT1]) / dx;
+      d[uMT2] -= dt * bm1 * (q0[qBT2]) / dx;
+      d[uERG] -= dt * bm1 * (uB) / dx;
+      d[uBN] -= dt * bm1 * (q0[qVN]) / dx;
+      d[uBT1] -= dt * bm1 * (q0[qVT1]) / dx;
+      d[uBT2] -= dt * bm1 * (q0[qVT2]) / dx;
+      if constexpr (EQ == EQGLM) {
+        const double sm1g = 0.5 * (q0[qSI] + qp1[qSI]);
+        d[uERG] -= dt * sm1g * (q0[qVN] * q0[qSI]) / dx;
+        d[uPSI] -= dt * sm1g * q0[qVN] / dx;
+      }
+    }
+    // dU_Cell + DivStateVectorComponent (VectorOps.cpp:624-644)
+#pragma unroll
+    for (int s = 0; s < NV; s++) {
+      const double u1 = (Fm[s] - Fp[s]) / dx;
+      d[s] += dt * u1;
+    }
+    from_sweep<NV, MHD>(ax, d, dU);
+  }
+
+  // ---- CellAdvanceTime (solver_eqn_hydro_adi.cpp:372-448, solver_eqn_mhd_adi.cpp:452-504, :822-844)
+  double u1[NV], Pf[NV];
+  if (a.fc.mp.present) {
+    double Pi[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) Pi[v] = P0[v];
+    E::apply_sCMA(Pi);
+    E::PtoU(Pi, u1, g);
+  }
+  else E::PtoU(P0, u1, g);
+#pragma unroll
+  for (int v = 0; v < NV; v++) u1[v] += dU[v];
+  E::UtoP(u1, Pf, a.fc.min_temp, g, a.fc.mp, err);
+  if (a.fc.mp.present) E::apply_sCMA(Pf);
+  if constexpr (EQ == EQGLM) Pf[qSI] *= a.glm_damp;  // GLMsource (eqns_mhd_adiabatic.cpp:651-660)
+  if (a.fc.mp.present) {
+    // grid_update_state_vector: T > MaxTemperature clamp (time_integrator.cpp:926-932)
+    const double T = Pf[qPG] * a.fc.mp.Mu_tot_over_kB / Pf[qRO];
+    if (T > a.max_temp) Pf[qPG] = Pf[qRO] * a.max_temp / a.fc.mp.Mu_tot_over_kB;
+  }
+#pragma unroll
+  for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v];
+  if (err) atomicOr(a.errword, err);
+}
+
+// ---------------------------------------------------------------------------
+// interface-flux test seam: FV_solver_base::InterCellFlux on n independent interfaces
+// ---------------------------------------------------------------------------
+template <int EQ, int NTR, int SOLVER>
+__global__ __launch_bounds__(256) void k_flux_test(const FluxTestArgs a)
+{
+  typedef Eqn<EQ, NTR> E;
+  typedef Flux<EQ, NTR, SOLVER> FX;
+  constexpr int NV = E::NV;
+  constexpr bool MHD = E::MHD;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double l[NV], r[NV], ls[NV], rs[NV], f[NV], ps[NV], fl[NV], pl[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    l[v] = a.Pl[(long)i * NV + v];
+    r[v] = a.Pr[(long)i * NV + v];
+  }
+  to_sweep<NV, MHD>(a.axis, l, ls);
+  to_sweep<NV, MHD>(a.axis, r, rs);
+  int err = 0;
+  FX::intercell_flux(ls, rs, f, ps, a.fc, a.aux[4 * i + 0], a.aux[4 * i + 1] != 0.0, err);
+  from_sweep<NV, MHD>(a.axis, f, fl);
+  from_sweep<NV, MHD>(a.axis, ps, pl);
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    a.F[(long)i * NV + v] = fl[v];
+    a.Pstar[(long)i * NV + v] = pl[v];
+  }
+  if (err) atomicOr(a.errword, err);
+}
+
+template <int EQ, int NTR, int SOLVER>
+static int stage_go(const StageArgs &a, hipStream_t s)
+{
+  const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
+  const long ntiles = (long)nbx * nby * a.g.ng[2];
+  const long nblocks = ((ntiles + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_stage<EQ, NTR, SOLVER>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+template <int EQ, int NTR, int SOLVER>
+static int flux_go(const FluxTestArgs &a, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_flux_test<EQ, NTR, SOLVER>), dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+#define PION_SOLVER_CASES_HD(FN, EQ, NTR, A, S)          \
+  switch (A.solver) {                                    \
+    case 0: return FN<EQ, NTR, 0>(A, S);                 \
+    case 1: return FN<EQ, NTR, 1>(A, S);                 \
+    case 2: return FN<EQ, NTR, 2>(A, S);                 \
+    case 3: return FN<EQ, NTR, 3>(A, S);                 \
+    case 4: return FN<EQ, NTR, 4>(A, S);                 \
+    case 5: return FN<EQ, NTR, 5>(A, S);                 \
+    case 6: return FN<EQ, NTR, 6>(A, S);                 \
+    case 8: return FN<EQ, NTR, 8>(A, S);                 \
+    default: return -1;                                  \
+  }
+#define PION_SOLVER_CASES_MHD(FN, EQ, NTR, A, S)         \
+  switch (A.solver) {                                    \
+    case 0: return FN<EQ, NTR, 0>(A, S);                 \
+    case 7: return FN<EQ, NTR, 7>(A, S);                 \
+    case 8: return FN<EQ, NTR, 8>(A, S);                 \
+    default: return -1;                                  \
+  }
+
+#if PION_EQSEL == 1
+#define PION_EQ EQEUL
+#define PION_CASES PION_SOLVER_CASES_HD
+#define PION_SUFFIX hd
+#elif PION_EQSEL == 2
+#define PION_EQ EQMHD
+#define PION_CASES PION_SOLVER_CASES_MHD
+#define PION_SUFFIX mhd
+#else
+#define PION_EQ EQGLM
+#define PION_CASES PION_SOLVER_CASES_MHD
+#define PION_SUFFIX glm
+#endif
+#define PION_CAT2(a, b) a##b
+#define PION_CAT(a, b) PION_CAT2(a, b)
+
+int PION_CAT(launch_stage_, PION_SUFFIX)(const StageArgs &a, hipStream_t s)
+{
+  switch (a.ntracer) {
+    case 0: PION_CASES(stage_go, PION_EQ, 0, a, s)
+    case 1: PION_CASES(stage_go, PION_EQ, 1, a, s)
+    case 2: PION_CASES(stage_go, PION_EQ, 2, a, s)
+    default: return -1;
+  }
+}
+int PION_CAT(launch_flux_test_, PION_SUFFIX)(const FluxTestArgs &a, hipStream_t s)
+{
+  switch (a.ntracer) {
+    case 0: PION_CASES(flux_go, PION_EQ, 0, a, s)
+    case 1: PION_CASES(flux_go, PION_EQ, 1, a, s)
+    case 2: PION_CASES(flux_go, PION_EQ, 2, a, s)
+    default: return -1;
+  }
+}
+
+#else  // PION_EQSEL == 0 : shared kernels -----------------------------------
+
+int launch_stage_hd(const StageArgs &a, hipStream_t s);
+int launch_stage_mhd(const StageArgs &a, hipStream_t s);
+int launch_stage_glm(const StageArgs &a, hipStream_t s);
+int launch_flux_test_hd(const FluxTestArgs &a, hipStream_t s);
+int launch_flux_test_mhd(const FluxTestArgs &a, hipStream_t s);
+int launch_flux_test_glm(const FluxTestArgs &a, hipStream_t s);
+
+int launch_stage(const StageArgs &a, hipStream_t s)
+{
+  if (a.eqntype == EQEUL) return launch_stage_hd(a, s);
+  if (a.eqntype == EQMHD) return launch_stage_mhd(a, s);
+  if (a.eqntype == EQGLM) return launch_stage_glm(a, s);
+  return -1;
+}
+int launch_flux_test(const FluxTestArgs &a, hipStream_t s)
+{
+  if (a.eqntype == EQEUL) return launch_flux_test_hd(a, s);
+  if (a.eqntype == EQMHD) return launch_flux_test_mhd(a, s);
+  if (a.eqntype == EQGLM) return launch_flux_test_glm(a, s);
+  return -1;
+}
+const char *stage_kernel_name(int, int, int) { return "k_stage"; }
+
+// ---------------------------------------------------------------------------
+// pre-pass: HLLD switch and H-correction.  One thread per cell INCLUDING ghosts
+// (the reference loops FirstPt_All..NextPt_All, solver_eqn_base.cpp:400-412).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
+{
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nc = a.g.ncell;
+  if (c >= nc) return;
+  int i[3];
+  i[0] = (int)(c % a.g.nga[0]);
+  i[1] = (int)((c / a.g.nga[0]) % a.g.nga[1]);
+  i[2] = (int)(c / ((long)a.g.nga[0] * a.g.nga[1]));
+  const double dx = a.g.dx;
+  double divv = 0.0, gradp = 0.0;
+  for (int v = 0; v < a.g.ndim; v++) {
+    const long st = (v == 0) ? 1 : ((v == 1) ? a.g.sy : a.g.sz);
+    // Divergence (VectorOps.cpp:377-439): missing neighbour -> this cell, one-sided dx
+    const long n = (i[v] > 0) ? c - st : c;
+    const long p = (i[v] < a.g.nga[v] - 1) ? c + st : c;
+    const double ddx = (n == c || p == c) ? dx : 2.0 * dx;
+    divv += (a.S[(2 + v) * nc + p] - a.S[(2 + v) * nc + n]) / ddx;
+    // GradZone (VectorOps.cpp:322-368) on the pressure
+    const double pp = a.S[1 * nc + p], pn = a.S[1 * nc + n];
+    gradp += fabs(pp - pn) / fmin(pp, pn);
+  }
+  if (a.divv) a.divv[c] = divv;
+  if (a.gradp) a.gradp[c] = gradp;
+  // solver_eqn_mhd_adi.cpp:171: (DivV<0 && Grad>5) of either cell switches the interface to HLL
+  a.hllflag[c] = (divv < 0. && gradp > 5.) ? 1 : 0;
+}
+
+// eta of interface (c | c+st) along each axis, stored at c (calc_Hcorrection; the last cell of a
+// column gets no value and keeps 0; first/last cells of a column have zero slope)
+template <int NVMAX>
+__global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
+{
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nc = a.g.ncell;
+  if (c >= nc) return;
+  int i[3];
+  i[0] = (int)(c % a.g.nga[0]);
+  i[1] = (int)((c / a.g.nga[0]) % a.g.nga[1]);
+  i[2] = (int)(c / ((long)a.g.nga[0] * a.g.nga[1]));
+  const double dx = a.g.dx, g = a.gamma;
+  const bool mhd = (a.eqntype != EQEUL);
+  const bool oa2 = (a.space_ooa == 2);
+  for (int ax = 0; ax < a.g.ndim; ax++) {
+    const long st = (ax == 0) ? 1 : ((ax == 1) ? a.g.sy : a.g.sz);
+    const int n = a.g.nga[ax], k = i[ax];
+    double eta = 0.0;
+    if (k < n - 1) {
+      // sweep-frame variables needed by maxspeed and v_n: rho, p, v_n, (B_n, B_t1, B_t2)
+      double eL[8], eR[8];
+      const int nvs = mhd ? 8 : 5;
+      for (int s = 0; s < 8; s++) {
+        if (s >= nvs) {
+          eL[s] = eR[s] = 0.0;
+          continue;
+        }
+        const double *b = a.S + (long)rotvar(ax, s) * nc + c;
+        const double q0 = b[0], q1 = b[st];
+        double s0 = 0.0, s1 = 0.0;
+        if (oa2) {
+          if (k > 0) s0 = avg_falle((q0 - b[-st]) / dx, (q1 - q0) / dx);   // first cell: zero slope
+          if (k + 1 < n - 1) s1 = avg_falle((q1 - q0) / dx, (b[2 * st] - q1) / dx);  // last cell: zero slope
+          eL[s] = q0 + s0 * dx * 0.5;
+          eR[s] = q1 - s1 * dx * 0.5;
+        }
+        else {
+          eL[s] = q0;
+          eR[s] = q1;
+        }
+      }
+      // set_Hcorrection (solver_eqn_base.cpp:579-599)
+      double msL, msR;
+      if (mhd) {
+        msL = Eqn<EQMHD, 0>::cfast(eL, g);
+        msR = Eqn<EQMHD, 0>::cfast(eR, g);
+      }
+      else {
+        msL = Eqn<EQEUL, 0>::chydro(eL, g);
+        msR = Eqn<EQEUL, 0>::chydro(eR, g);
+      }
+      eta = 0.5 * (fabs(eR[qVN] - eL[qVN]) + fabs(msR - msL));
+    }
+    a.eta[ax * nc + c] = eta;
+  }
+}
+
+int launch_prepass(const PrepassArgs &a, hipStream_t s)
+{
+  const unsigned nb = (unsigned)((a.g.ncell + 255) / 256);
+  if (a.hllflag) hipLaunchKernelGGL(k_prepass_hlld, dim3(nb), dim3(256), 0, s, a);
+  if (a.eta) hipLaunchKernelGGL((k_prepass_hcorr<8>), dim3(nb), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// time-step reduction
+// ---------------------------------------------------------------------------
+PDEV double wave_min(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = (o < v) ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_dt(const DtArgs a)
+{
+  const long nc = a.g.ncell;
+  const long non = (long)a.g.ng[0] * a.g.ng[1] * a.g.ng[2];
+  double tdyn = 1.e100, tmp = 1.0e99;
+  int err = 0;
+  const bool mhd = (a.eqntype != EQEUL);
+  const double g = a.gamma;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < non; k += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(k % a.g.ng[0]), iy = (int)((k / a.g.ng[0]) % a.g.ng[1]),
+              iz = (int)(k / ((long)a.g.ng[0] * a.g.ng[1]));
+    const long c = (long)(ix + a.g.nbc[0]) + a.g.sy * (iy + a.g.nbc[1]) + a.g.sz * (iz + a.g.nbc[2]);
+    const uint8_t fl = a.flags[c];
+    if ((fl & 8 /*TIMESTEP*/) && !(fl & 2 /*ISBD*/)) {
+      // CellTimeStep: solver_eqn_hydro_adi.cpp:460-502 / solver_eqn_mhd_adi.cpp:516-582
+      double p[8];
+      const int nvs = mhd ? 8 : 5;
+      for (int v = 0; v < 8; v++) p[v] = (v < nvs) ? a.P[v * nc + c] : 0.0;
+      double temp;
+      if (!mhd) {
+        temp = 0.0;
+        for (int v = 0; v < a.g.ndim; v++) temp += p[2 + v] * p[2 + v];
+        temp = sqrt(temp);
+        temp += Eqn<EQEUL, 0>::chydro(p, g);
+      }
+      else {
+        temp = fabs(p[2]);
+        if (a.g.ndim > 1) temp = dmax(temp, fabs(p[3]));
+        if (a.g.ndim > 2) temp = dmax(temp, fabs(p[4]));
+        if (a.g.ndim == 1) temp += Eqn<EQMHD, 0>::cfast(p, g);
+        else {
+          int newdir = 0;
+          if (fabs(p[6]) < fabs(p[5])) {
+            newdir = 1;
+            if (fabs(p[7]) < fabs(p[6])) newdir = 2;
+          }
+          else if (fabs(p[7]) < fabs(p[5])) newdir = 2;
+          double u1[8];
+          to_sweep<8, true>(newdir, p, u1);  // eqns_mhd_ideal::rotate(u1,XX,newdir)
+          temp += Eqn<EQMHD, 0>::cfast(u1, g);
+        }
+      }
+      double t = a.g.dx / temp;
+      t *= a.cfl;
+      if (!(t > 0.0)) err |= ERR_BAD_DT;
+      tdyn = (t < tdyn) ? t : tdyn;
+    }
+    if (a.do_mp && !(fl & 2) && (fl & 16)) {
+      const double t = Cooling::timescale(a.cool, a.Ph[0 * nc + c], a.Ph[1 * nc + c], g);
+      tmp = (t < tmp) ? t : tmp;
+    }
+  }
+  tdyn = wave_min(tdyn);
+  tmp = wave_min(tmp);
+  if ((threadIdx.x & 63) == 0) {
+    // positive doubles order like their bit patterns
+    atomicMin(&a.result[0], (unsigned long long)__double_as_longlong(tdyn));
+    atomicMin(&a.result[1], (unsigned long long)__double_as_longlong(tmp));
+  }
+  if (err) atomicOr(a.errword, err);
+}
+
+int launch_dt(const DtArgs &a, hipStream_t s)
+{
+  const long non = (long)a.g.ng[0] * a.g.ng[1] * a.g.ng[2];
+  long nb = (non + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_dt, dim3((unsigned)nb), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// cooling test seams
+// ---------------------------------------------------------------------------
+__global__ void k_cool_update(const CoolTestArgs a)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  int err = 0;
+  const double *p = a.Pin + (long)i * a.nvar;
+  double *o = a.Pout + (long)i * a.nvar;
+  for (int v = 0; v < a.nvar; v++) o[v] = p[v];
+  o[1] = Cooling::time_update(a.cool, p[0], p[1], a.dt, a.gamma, err);
+  if (err) atomicOr(a.errword, err);
+}
+__global__ void k_cool_edot(const CoolTestArgs a)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  a.edot[i] = Cooling::edot(a.cool, a.rho[i], a.T[i]);
+}
+int launch_cool_update(const CoolTestArgs &a, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_cool_update, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+int launch_cool_edot(const CoolTestArgs &a, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_cool_edot, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+#endif  // PION_EQSEL
+
+}  // namespace PION_FPNS
+}  // namespace pion

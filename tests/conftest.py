@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_oracle():
+    """The oracle is test infrastructure; make sure it is built (seconds)."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
