@@ -34,13 +34,14 @@ namespace PION_FPNS {
 // helpers
 // ---------------------------------------------------------------------------
 // SoA variable of sweep-frame slot s for a sweep along ax (run-time version of gvar<>)
+template <bool MHD>
 PDEV int rotvar(const int ax, const int s)
 {
   if (s >= 2 && s <= 4) {
     int k = (s - 2) + ax;
     return 2 + (k >= 3 ? k - 3 : k);
   }
-  if (s >= 5 && s <= 7) {
+  if (MHD && s >= 5 && s <= 7) {
     int k = (s - 5) + ax;
     return 5 + (k >= 3 ? k - 3 : k);
   }
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
       double qm2[NV], qp2[NV];
 #pragma unroll
       for (int s = 0; s < NV; s++) {
-        const double *b = a.S + (long)rotvar(ax, s) * nc + c;
+        const double *b = a.S + (long)rotvar<MHD>(ax, s) * nc + c;
         qm1[s] = b[-st];
         q0[s] = b[0];
         qp1[s] = b[st];
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
           eL[s] = eR[s] = 0.0;
           continue;
         }
-        const double *b = a.S + (long)rotvar(ax, s) * nc + c;
+        const double *b = a.S + (long)(mhd ? rotvar<true>(ax, s) : rotvar<false>(ax, s)) * nc + c;
         const double q0 = b[0], q1 = b[st];
         double s0 = 0.0, s1 = 0.0;
         if (oa2) {

@@ -50,7 +50,7 @@ def run_pair(cfg, P, nsteps, strict=True, tol=0.0, first_dt_limit=None, setup=No
                 assert np.max(np.abs(a - b) / scale) <= tol, np.max(np.abs(a - b) / scale)
 
 
-HD_SOLVERS = [abi.FLUX_RSlinear, abi.FLUX_RSroe, abi.FLUX_RSroe_pv, abi.FLUX_FVS, abi.FLUX_RS_HLL]
+HD_SOLVERS = [abi.FLUX_RSroe, abi.FLUX_RSroe_pv, abi.FLUX_FVS, abi.FLUX_RS_HLL]
 
 
 @pytest.mark.parametrize("solver", HD_SOLVERS)
@@ -69,7 +69,7 @@ def test_hd_roe_viscosities_strict(av, ndim):
     run_pair(cfg, P, 3)
 
 
-@pytest.mark.parametrize("solver", [abi.FLUX_RSexact, abi.FLUX_RShybrid])
+@pytest.mark.parametrize("solver", [abi.FLUX_RSlinear, abi.FLUX_RSexact, abi.FLUX_RShybrid])
 def test_hd_exact_hybrid(solver):
     # exp/log/pow of the device maths library differ from glibc in the last bits
     cfg, P = problems.hd_blast_octant(32, 2, solver=solver, strict_fp=1, nzones=3.0)
@@ -109,7 +109,7 @@ def test_fast_mode_tolerance():
     run_pair(cfg, P, 3, strict=False, tol=1e-11)
 
 
-@pytest.mark.parametrize("eq,solvers", [(abi.EQEUL, [0, 1, 4, 5, 6, 8]), (abi.EQMHD, [0, 7, 8]), (abi.EQGLM, [0, 7, 8])])
+@pytest.mark.parametrize("eq,solvers", [(abi.EQEUL, [0, 1, 2, 3, 4, 5, 6, 8]), (abi.EQMHD, [0, 7, 8]), (abi.EQGLM, [0, 7, 8])])
 def test_interface_flux_strict(eq, solvers):
     rng = np.random.default_rng(7)
     for sv in solvers:
@@ -128,8 +128,13 @@ def test_interface_flux_strict(eq, solvers):
                     for ax in range(3):
                         Fg, _ = g.interface_flux(ax, L, R, aux, dt=0.01)
                         Fo, _ = o.interface_flux(ax, L, R, aux, dt=0.01)
-                        if sv in (0, 5, 8) and eq == abi.EQEUL and ntr:
-                            # tracer-free part only matters; tracer flux is upwinded identically
-                            pass
-                        assert np.array_equal(Fg, Fo, equal_nan=True), (eq, sv, ntr, av, ax,
-                                                                         np.nanmax(np.abs(Fg - Fo)))
+                        if eq == abi.EQEUL and sv in (1, 2, 3):
+                            # rarefaction/cavitation branches use exp/log/pow (riemann.cpp:829-963):
+                            # device libm vs glibc differ in the last bits
+                            ok = np.isfinite(Fo)
+                            assert np.array_equal(np.isfinite(Fg), ok)
+                            sc = np.abs(Fo[ok]).max()
+                            assert np.max(np.abs(Fg[ok] - Fo[ok])) <= 1e-12 * sc
+                        else:
+                            assert np.array_equal(Fg, Fo, equal_nan=True), (eq, sv, ntr, av, ax,
+                                                                             np.nanmax(np.abs(Fg - Fo)))
