@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X flux-update path.
+
+Workload: 3-D GLM-MHD Stone blast wave, 512^3, HLLD + FKJ98
+viscosity, periodic, second order in space and time, fp64.  One "step" = one full
+second-order time step of the reference's time loop: calculate_timestep (CFL
+reduction) + advance_time (2 fused stages + 2 boundary updates).
+
+  python bench.py --gpus N --steps K --warmup W
+
+N>1 is launched by torch.distributed.run, one rank per GPU; the 512^3 grid is split
+into z-slabs (strong scaling) with RCCL halo exchange.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from pion_amd import abi, driver, lib, problems, slab  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(n, eqntype, solver, budget_s=15.0):
+    """CPU 'port' baseline: the scalar oracle (oracle/liboracle.so, single thread) on the same
+    problem shrunk to n^3, timed for a bounded number of steps."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_backends import CpuSim, have_oracle
+    if not have_oracle():
+        return None
+    cfg, P = problems.mhd_blastwave(n, 3, eqntype, solver, strict_fp=1)
+    with CpuSim(cfg, "orc") as o:
+        sc = driver.SimControl(o, cfg)
+        sc.init(P)
+        sc.calculate_timestep()
+        sc.advance_time()  # untimed first step
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            sc.calculate_timestep()
+            sc.advance_time()
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or steps >= 50:
+                break
+    return {"value": n ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of the same GLM-MHD HLLD blast on %d^3 (%.1f s, 1 thread, oracle/liboracle.so)"
+                      % (steps, n, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=512, help="cells per axis (headline: 512)")
+    ap.add_argument("--eqn", default="glm", choices=["glm", "mhd"])
+    ap.add_argument("--strict", type=int, default=0, help="1 = bit-parity kernels (no FMA contraction)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    eq = abi.EQGLM if args.eqn == "glm" else abi.EQMHD
+    solver = abi.FLUX_RS_HLLD
+
+    comm = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
+    n = args.n
+    cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
+    cfg_g.dx = 1.0 / n
+    cfg = slab.slab_config(cfg_g, rank, world)
+    P = problems.fill_mhd_blastwave(cfg)
+
+    sim = lib.GpuSim(cfg, local_rank)
+    if world > 1:
+        comm = slab.SlabComm(rank, world, True, sim.halo_count(), torch.device("cuda", local_rank))
+    sc = driver.SimControl(sim, cfg, comm=comm)
+    sc.init(P)
+    del P
+
+    def barrier():
+        sim.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        sc.calculate_timestep()
+        sc.advance_time()
+    sim.enable_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc.calculate_timestep()
+        sc.advance_time()
+    barrier()
+    el = time.perf_counter() - t0
+    tm = sim.get_timing()
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        ncell = n ** 3
+        value = ncell * args.steps / el / 1e6
+        nvar = cfg.nvar
+        # algorithmic bytes of one stage launch on this rank: a step moves 5*nvar*8 B per
+        # cell in two launches (stage 1: read P, write Ph; stage 2: read P and Ph, write P)
+        cells_rank = cfg.ng[0] * cfg.ng[1] * cfg.ng[2]
+        alg_bytes = 2.5 * nvar * 8 * cells_rank
+        achieved = alg_bytes / (tm["stage_ms"] * 1e-3) / 1e9 if tm["stage_ms"] > 0 else 0.0
+        out = {
+            "metric": "Mcell-updates/s on 3D ideal-MHD 512^3 uniform grid; achieved HBM GB/s vs peak",
+            "value": value, "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
+                                   % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
+                       "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world,
+                       "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_stage<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage<MHD,0,HLLD>",
+                         "kernel_ms": tm["stage_ms"], "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
+                         "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, eq, solver)
+        print(json.dumps(out))
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,14 +45,22 @@ def mhd_blastwave(n, ndim=3, eqntype=abi.EQGLM, solver=abi.FLUX_RS_HLLD, strict_
                           gamma=5.0 / 3.0, cfl=0.24, xmin=(-0.5, -0.5, -0.5), xmax=(0.5, 0.5, 0.5),
                           bcs=["periodic"] * (2 * ndim),
                           refvec=[1.0, 0.1, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], strict_fp=strict_fp)
+    return cfg, fill_mhd_blastwave(cfg)
+
+
+def fill_mhd_blastwave(cfg):
+    """IC of mhd_blastwave for any (global or slab) configuration; built plane-wise so that a
+    512^3 slab does not need several full-size temporaries."""
     P = alloc(cfg)
-    X, Y, Z = mesh(cfg)
-    r2 = X * X + (Y * Y if ndim > 1 else 0.0) + (Z * Z if ndim > 2 else 0.0)
+    x, y, z = cell_centres(cfg)
     P[abi.RO] = 1.0
-    P[abi.PG] = np.where(r2 < 0.1 * 0.1, 10.0, 0.1)
     P[abi.BX] = 1.0 / math.sqrt(2.0)
     P[abi.BY] = 1.0 / math.sqrt(2.0)
-    return cfg, P
+    xy2 = x[None, :] ** 2 + (y[:, None] ** 2 if cfg.ndim > 1 else 0.0)
+    for k in range(z.size):
+        r2 = xy2 + (z[k] ** 2 if cfg.ndim > 2 else 0.0)
+        P[abi.PG, k] = np.where(r2 < 0.1 * 0.1, 10.0, 0.1)
+    return P
 
 
 def mhd_smooth(n, ndim=3, eqntype=abi.EQGLM, solver=abi.FLUX_RS_HLLD, bcs=None, strict_fp=1,

@@ -1,0 +1,103 @@
+"""z-slab decomposition over the GPUs of one node (one process per GPU).
+
+Replaces, for this path, the reference's source/decomposition/MCMD_control.cpp:231-309
+(slab decomposition along one axis) and the packed MPI halo exchange of
+source/comms/comm_mpi.cpp:287-636 / boundaries/MCMD_boundaries.cpp:122-237:
+
+  * rank r owns z in [r*Nz/N, (r+1)*Nz/N) plus nbc ghost planes either side;
+  * after every stage, once the local x/y (and physical z) boundaries are filled, the
+    nbc on-grid planes next to each internal z face -- full x-y extent INCLUDING the
+    x/y ghosts, which reproduces the reference's X->Y->Z corner fill -- are copied to a
+    contiguous device buffer and sent to the neighbour with torch.distributed P2P
+    (backend nccl = RCCL over xGMI on the GPUs, gloo on CPU for tests);
+  * the time step is a 2-double all-reduce(min) (sim_control_MPI.cpp:503-504).
+The reference sends Ph only and copies P=Ph locally on the full step; here the array
+that was just written (Ph after a half step, P after a full step) is the one exchanged.
+"""
+from . import abi
+
+
+def slab_config(cfg_global, rank, world):
+    """Per-rank configuration of a z-slab of the global problem."""
+    import copy
+    if cfg_global.ndim != 3:
+        raise ValueError("slab decomposition needs a 3-D grid")
+    nz = cfg_global.ng[2]
+    if nz % world != 0:
+        raise ValueError("NGridZ=%d not divisible by %d ranks" % (nz, world))
+    cfg = copy.deepcopy(cfg_global)
+    nzl = nz // world
+    cfg.ng[2] = nzl
+    cfg.xmin[2] = cfg_global.xmin[2] + rank * nzl * cfg_global.dx
+    periodic = cfg_global.bc_type[4] == abi.BC_PERIODIC
+    if world > 1:
+        if periodic or rank > 0:
+            cfg.bc_type[4] = abi.BC_SLAB
+        if periodic or rank < world - 1:
+            cfg.bc_type[5] = abi.BC_SLAB
+    return cfg
+
+
+def slab_slice(P_global, cfg_global, rank, world):
+    """The rank's part [nvar][nzl+2nbc][ny_all][nx_all] of a global SoA array (ghost planes
+    taken from the global array; they are overwritten by the first boundary update)."""
+    nb = cfg_global.nbc
+    nzl = cfg_global.ng[2] // world
+    z0 = rank * nzl
+    return P_global[:, z0:z0 + nzl + 2 * nb].copy()
+
+
+class SlabComm:
+    """Halo exchange + dt reduction for one rank.  `make_buffer(n)` returns a flat float64
+    tensor on the device the backend computes on; backend.pack_halo/unpack_halo take
+    (which, face, tensor.data_ptr())."""
+
+    def __init__(self, rank, world, periodic, halo_count, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = rank, world
+        self.up = (rank + 1) % world if (periodic or rank < world - 1) else None
+        self.down = (rank - 1) % world if (periodic or rank > 0) else None
+        if world == 1:
+            self.up = self.down = None
+        mk = lambda: torch.empty(halo_count, dtype=torch.float64, device=device)
+        self.send_up, self.send_down, self.recv_up, self.recv_down = mk(), mk(), mk(), mk()
+        self.dtbuf = torch.empty(2, dtype=torch.float64, device=device)
+
+    def exchange(self, sim, which):
+        dist = self.dist
+        if self.up is None and self.down is None:
+            return
+        ops = []
+        if self.up is not None:
+            sim.pack_halo(which, 5, self.send_up.data_ptr())      # my top on-grid planes
+        if self.down is not None:
+            sim.pack_halo(which, 4, self.send_down.data_ptr())    # my bottom on-grid planes
+        sim.synchronize()
+        # order matters when up == down (2 ranks, periodic): first message = "top" planes
+        if self.up is not None:
+            ops.append(dist.P2POp(dist.isend, self.send_up, self.up))
+        if self.down is not None:
+            ops.append(dist.P2POp(dist.irecv, self.recv_down, self.down))
+        if self.down is not None:
+            ops.append(dist.P2POp(dist.isend, self.send_down, self.down))
+        if self.up is not None:
+            ops.append(dist.P2POp(dist.irecv, self.recv_up, self.up))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.recv_down.is_cuda:
+            self.torch.cuda.current_stream().synchronize()
+        if self.down is not None:
+            sim.unpack_halo(which, 4, self.recv_down.data_ptr())  # neighbour's top -> my ZN ghosts
+        if self.up is not None:
+            sim.unpack_halo(which, 5, self.recv_up.data_ptr())    # neighbour's bottom -> my ZP ghosts
+
+    def allreduce_min(self, t_dyn, t_mp):
+        if self.world == 1:
+            return t_dyn, t_mp
+        self.dtbuf[0] = t_dyn
+        self.dtbuf[1] = t_mp
+        self.dist.all_reduce(self.dtbuf, op=self.dist.ReduceOp.MIN)
+        v = self.dtbuf.tolist()
+        return v[0], v[1]
