@@ -87,6 +87,49 @@ class CpuSim:
         self._chk(self._f("download")(self.h, C.c_int(which), _p(out)), "download")
         return out.reshape(self.shape)
 
+    def upload_which(self, which, A):
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1)
+        self._chk(self._f("upload_which")(self.h, C.c_int(which), _p(A)), "upload_which")
+
+    # slab halos on the CPU (oracle only): buffers are numpy arrays passed by address
+    def halo_count(self):
+        nga = abi.ng_all(self.cfg)
+        return self.nvar * self.cfg.nbc * nga[0] * nga[1]
+
+    def _halo_view(self, ptr):
+        n = self.halo_count()
+        nga = abi.ng_all(self.cfg)
+        buf = (C.c_double * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float64).reshape(self.nvar, self.cfg.nbc, nga[1], nga[0])
+
+    def pack_halo(self, which, face, ptr):
+        A = self.download(which)
+        nb, nz = self.cfg.nbc, self.cfg.ng[2]
+        v = self._halo_view(ptr)
+        v[...] = A[:, nb:2 * nb] if face == 4 else A[:, nz:nz + nb]
+
+    def unpack_halo(self, which, face, ptr):
+        A = self.download(which)
+        nb, nz = self.cfg.nbc, self.cfg.ng[2]
+        v = self._halo_view(ptr)
+        if face == 4:
+            A[:, 0:nb] = v
+        else:
+            A[:, nb + nz:nb + nz + nb] = v
+        self.upload_which(which, A)
+        if which == 0:
+            # full step: the reference sets P=Ph in the received ghost cells
+            # (MCMD_boundaries.cpp:215-224); the oracle keeps both arrays, so mirror it
+            B = self.download(1)
+            if face == 4:
+                B[:, 0:nb] = v
+            else:
+                B[:, nb + nz:nb + nz + nb] = v
+            self.upload_which(1, B)
+
+    def synchronize(self):
+        pass
+
     def flags(self):
         out = np.empty(self.ncell, dtype=np.uint8)
         self._f("get_flags")(self.h, out.ctypes.data_as(C.POINTER(C.c_ubyte)))

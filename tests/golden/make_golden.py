@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from oracle/_ref/libpion_ref.so, i.e. from the
+REFERENCE's own solver objects (compiled from /root/reference by `make -C oracle ref`) driven by
+oracle/ref_harness.cpp.  Run in the build container only (the reference does not travel):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Fixtures are data: seeded inputs and the reference's outputs, stored as compressed .npz.
+  flux_kat.npz      InterCellFlux known-answer vectors: every flux solver the path supports
+                    (HD: LF, linear, exact, hybrid, Roe-CV (+H-corr eta), Roe-PV, FVS, HLL;
+                     MHD and GLM-MHD: LF, HLL, HLLD incl. the HLL switch), with and without
+                    tracers and FKJ98 viscosity, along all three axes, 160 state pairs each
+                    including degenerate pairs (equal states, Bx=0, Bt=0, supersonic, vacuum).
+  cell_kat.npz      CellAdvanceTime and CellTimeStep vectors (incl. negative-pressure repair,
+                    with and without a microphysics object).
+  steps.npz         whole-grid dumps after 2 second-order steps (and per-stage aux data) for small
+                    grids: HD Roe 3-D octant blast (reflecting/outflow), HD FVS 2-D with tracer,
+                    HD Roe + H-correction 2-D, ideal-MHD HLLD 2-D periodic, GLM-MHD HLLD 3-D
+                    periodic blast, GLM-MHD mixed outflow/one-way/reflecting 2-D, DMR 2-D, LF 1st order.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from pion_amd import abi, driver, problems  # noqa: E402
+from cpu_backends import CpuSim  # noqa: E402
+import golden_cases as gc  # noqa: E402
+
+
+def main():
+    rng = np.random.default_rng(20240611)
+    # ---- interface-flux KATs
+    out = {}
+    for (eq, sv, ntr, av) in gc.flux_cases():
+        cfg = gc.flux_cfg(eq, sv, ntr, av)
+        L, R = problems.random_states(rng, gc.NFLUX, eq, ntr)
+        aux = np.zeros((gc.NFLUX, 4))
+        if av == abi.AV_HCORR_FKJ98:
+            aux[:, 0] = rng.uniform(0, 2, gc.NFLUX)
+        if sv == abi.FLUX_RS_HLLD:
+            aux[:, 1] = rng.uniform(0, 1, gc.NFLUX) < 0.3
+        key = gc.flux_key(eq, sv, ntr, av)
+        out[key + "_L"], out[key + "_R"], out[key + "_aux"] = L, R, aux
+        with CpuSim(cfg, "ref") as r:
+            r.set_glm_speeds(gc.GLM_DT, cfg.dx, 0.25 / cfg.dx)
+            for ax in range(3):
+                F, _ = r.interface_flux(ax, L, R, aux, dt=gc.GLM_DT)
+                out[key + "_F%d" % ax] = F
+    np.savez_compressed(os.path.join(HERE, "flux_kat.npz"), **out)
+
+    # ---- cell KATs
+    out = {}
+    for (eq, ntr, cool) in gc.cell_cases():
+        cfg = gc.cell_cfg(eq, ntr, cool)
+        P, dU = gc.cell_inputs(rng, cfg)
+        key = gc.cell_key(eq, ntr, cool)
+        with CpuSim(cfg, "ref") as r:
+            r.set_glm_speeds(gc.GLM_DT, cfg.dx, 0.25 / cfg.dx)
+            out[key + "_P"], out[key + "_dU"] = P, dU
+            out[key + "_Pf"] = r.cell_advance(P, dU, fv_dt=gc.GLM_DT)
+            out[key + "_dt"] = r.cell_timestep(P)
+    np.savez_compressed(os.path.join(HERE, "cell_kat.npz"), **out)
+
+    # ---- whole-grid steps
+    out = {}
+    for name in gc.STEP_CASES:
+        cfg, P = gc.step_case(name)
+        with CpuSim(cfg, "ref") as r:
+            sc = driver.SimControl(r, cfg)
+            sc.init(P)
+            out[name + "_bc"] = r.download(0).astype(np.float64)
+            dts = []
+            for _ in range(gc.NSTEPS):
+                dts.append(sc.calculate_timestep())
+                sc.advance_time()
+            out[name + "_dt"] = np.array(dts)
+            out[name + "_P"] = r.download(0)
+    np.savez_compressed(os.path.join(HERE, "steps.npz"), **out)
+    for f in ("flux_kat.npz", "cell_kat.npz", "steps.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""Definitions of the golden-fixture cases, shared by tests/golden/make_golden.py (which runs the
+reference) and the tests (which run the oracle / the GPU on the same inputs)."""
+import numpy as np
+
+from pion_amd import abi, problems
+
+NFLUX = 160
+GLM_DT = 0.01
+NSTEPS = 2
+
+
+def flux_cases():
+    cases = []
+    for sv in (0, 1, 2, 3, 4, 5, 6, 8):
+        for ntr in (0, 2):
+            for av in ((0, 1, 4) if sv == 4 else (1,)):
+                cases.append((abi.EQEUL, sv, ntr, av))
+    for eq in (abi.EQMHD, abi.EQGLM):
+        for sv in (0, 7, 8):
+            for ntr in (0, 1):
+                for av in (0, 1):
+                    cases.append((eq, sv, ntr, av))
+    return cases
+
+
+def flux_cfg(eq, sv, ntr, av, strict_fp=1):
+    return abi.make_config(3, [4, 4, 4], eq, sv, ntracer=ntr, artvisc=av, xmax=(1, 1, 1), strict_fp=strict_fp)
+
+
+def flux_key(eq, sv, ntr, av):
+    return "eq%d_s%d_t%d_av%d" % (eq, sv, ntr, av)
+
+
+def cell_cases():
+    return [(abi.EQEUL, 0, 0), (abi.EQEUL, 1, 0), (abi.EQEUL, 1, 8), (abi.EQMHD, 0, 0), (abi.EQGLM, 0, 0),
+            (abi.EQGLM, 1, 8)]
+
+
+def cell_cfg(eq, ntr, cool, strict_fp=1):
+    solver = abi.FLUX_RSroe if eq == abi.EQEUL else abi.FLUX_RS_HLLD
+    return abi.make_config(3, [4, 4, 4], eq, solver, ntracer=ntr, xmax=(1, 1, 1), cooling=cool,
+                           min_temp=1e-2, max_temp=1e9, strict_fp=strict_fp)
+
+
+def cell_key(eq, ntr, cool):
+    return "eq%d_t%d_c%d" % (eq, ntr, cool)
+
+
+def cell_inputs(rng, cfg, n=200):
+    L, _ = problems.random_states(rng, n, cfg.eqntype, cfg.ntracer)
+    # make the states CGS-like when a microphysics object is present so that temperatures are sane
+    if cfg.cooling:
+        L[:, abi.RO] *= 1e-24
+        L[:, abi.PG] *= 1e-12
+    dU = np.zeros_like(L)
+    scale = np.abs(L).max(axis=0)
+    dU[:] = rng.normal(0, 0.05, L.shape) * scale
+    dU[:, abi.RHO] = np.abs(dU[:, abi.RHO]) * 0.1
+    # a third of the cells lose enough energy to need the negative-pressure repair
+    k = n // 3
+    dU[:k, abi.ERG] = -3.0 * (L[:k, abi.PG] / (cfg.gamma - 1.0) + 0.5 * L[:k, abi.RO] * (L[:k, 2:5] ** 2).sum(axis=1))
+    return L, dU
+
+
+STEP_CASES = ["hd_roe_3d", "hd_fvs_2d_tr", "hd_roe_hcorr_2d", "hd_hll_1d", "mhd_hlld_2d", "glm_hlld_3d",
+              "glm_mixed_2d", "dmr_2d", "hd_lf_oa1_3d"]
+
+
+def step_case(name, strict_fp=1):
+    if name == "hd_roe_3d":
+        return problems.hd_blast_octant(12, 3, solver=abi.FLUX_RSroe, strict_fp=strict_fp, nzones=3.0)
+    if name == "hd_fvs_2d_tr":
+        return problems.hd_blast_octant(24, 2, solver=abi.FLUX_FVS, ntracer=1, strict_fp=strict_fp, nzones=3.0)
+    if name == "hd_roe_hcorr_2d":
+        return problems.hd_blast_octant(24, 2, solver=abi.FLUX_RSroe, artvisc=abi.AV_HCORR_FKJ98,
+                                        strict_fp=strict_fp, nzones=3.0)
+    if name == "hd_hll_1d":
+        return problems.hd_blast_octant(64, 1, solver=abi.FLUX_RS_HLL, strict_fp=strict_fp, nzones=3.0)
+    if name == "mhd_hlld_2d":
+        return problems.mhd_blastwave(24, 2, abi.EQMHD, abi.FLUX_RS_HLLD, strict_fp=strict_fp)
+    if name == "glm_hlld_3d":
+        return problems.mhd_blastwave(12, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=strict_fp)
+    if name == "glm_mixed_2d":
+        return problems.mhd_smooth(20, 2, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=strict_fp,
+                                   bcs=["outflow", "one-way-outflow", "reflecting", "outflow"])
+    if name == "dmr_2d":
+        return problems.double_mach_reflection(52, strict_fp=strict_fp)
+    if name == "hd_lf_oa1_3d":
+        cfg, P = problems.hd_blast_octant(10, 3, solver=abi.FLUX_LF, strict_fp=strict_fp, nzones=3.0)
+        cfg.sp_ooa = cfg.tm_ooa = 1
+        return cfg, P
+    raise KeyError(name)
