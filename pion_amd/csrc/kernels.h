@@ -50,6 +50,8 @@ struct StageArgs {
   double dt;          // stage dt (= FV_dt)
   double glm_damp;    // exp(-FV_dt*chyp*cr), evaluated on the host
   double max_temp;    // EP.MaxTemperature
+  int use_march;      // 1: k_stage_march (3-D, nbc>=2), 0: k_stage (cell per thread)
+  int zchunk;         // planes per wavefront in k_stage_march
   CoolDev cool;
 };
 

@@ -344,9 +344,12 @@ __global__ __launch_bounds__(256) void k_flux_test(const FluxTestArgs a)
   if (err) atomicOr(a.errword, err);
 }
 
+#include "stage_march.h"
+
 template <int EQ, int NTR, int SOLVER>
 static int stage_go(const StageArgs &a, hipStream_t s)
 {
+  if (a.use_march && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_march_go<EQ, NTR, SOLVER>(a, s);
   const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
   const long ntiles = (long)nbx * nby * a.g.ng[2];
   const long nblocks = ((ntiles + 7) / 8) * 8;

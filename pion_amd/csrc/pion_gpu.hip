@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -202,6 +203,7 @@ struct Handle {
   bool timing = false;
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
+  int use_march = 1, zchunk = 32;
 };
 
 #define HCHECK(h, call)                                                            \
@@ -287,6 +289,8 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
 
   Handle *h = new Handle;
   h->cfg = *cfg;
+  if (const char *e = getenv("PION_STAGE_KERNEL")) h->use_march = (strcmp(e, "cell") != 0);
+  if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 32;
   h->device = device;
   if (hipSetDevice(device) != hipSuccess) {
     delete h;
@@ -721,6 +725,8 @@ int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_ste
   a.glm_damp = exp(-dt_stage * h->glm_chyp * h->glm_cr);
   a.max_temp = cfg.max_temp;
   a.cool = h->cool;
+  a.use_march = h->use_march;
+  a.zchunk = h->zchunk;
   time_begin(h, 0);
   rc = cfg.strict_fp ? fp_strict::launch_stage(a, h->stream) : fp_fast::launch_stage(a, h->stream);
   time_end(h, 0);
