@@ -136,6 +136,67 @@ def double_mach_reflection(nx, solver=abi.FLUX_RSroe, strict_fp=0):
     return cfg, P
 
 
+MSUN_PER_YR = 1.989e33 / 3.156e7   # g/s per Msun/yr (pconst.Msun()/pconst.year())
+
+
+def wind_cells(cfg, pos, radius, mdot_msun_yr, vinf_kms, Tw, Rstar, tracers):
+    """Stellar-wind boundary cells and their fixed states for a 3-D Cartesian grid:
+    membership = every cell (ghosts included) whose centre is within `radius` of the source
+    (boundaries/stellar_wind_boundaries.cpp:200-240); state = stellar_wind::
+    set_wind_cell_reference_state (grid/stellar_wind_BC.cpp:375-470): rho = Mdot/(4 pi r^2 v_inf),
+    adiabatic p from the surface temperature, radial velocity v_inf; cells inside 0.75 radius
+    carry rho = p = 1e-31.  Returns (cell ids, states[n, nvar])."""
+    kB, m_p = 1.38064852e-16, 1.672621898e-24
+    mdot = mdot_msun_yr * MSUN_PER_YR
+    vinf = vinf_kms * 1.0e5
+    x, y, z = cell_centres(cfg)
+    Z, Y, X = np.meshgrid(z - pos[2], y - pos[1], x - pos[0], indexing="ij")
+    dist = np.sqrt(X * X + Y * Y + Z * Z)
+    sel = dist <= radius
+    idx = np.flatnonzero(sel.reshape(-1))
+    d = dist.reshape(-1)[idx]
+    st = np.zeros((idx.size, cfg.nvar))
+    rho = 1.0 / d
+    rho = rho * rho
+    rho = rho * (mdot / (vinf * 4.0 * math.pi))
+    pg = kB * Tw / m_p
+    pg = pg * math.exp((cfg.gamma - 1.0) * math.log(4.0 * math.pi * Rstar * Rstar * vinf / mdot))
+    pg = pg * np.exp(cfg.gamma * np.log(rho))
+    inner = d < 0.75 * radius
+    st[:, abi.RO] = np.where(inner, 1.0e-31, rho)
+    st[:, abi.PG] = np.where(inner, 1.0e-31, pg)
+    st[:, abi.VX] = vinf * X.reshape(-1)[idx] / d
+    st[:, abi.VY] = vinf * Y.reshape(-1)[idx] / d
+    st[:, abi.VZ] = vinf * Z.reshape(-1)[idx] / d
+    base = cfg.nvar - cfg.ntracer
+    for t in range(cfg.ntracer):
+        st[:, base + t] = tracers[t]
+    return idx.astype(np.int64), st
+
+
+def wind3d(n, strict_fp=0):
+    """M3: test_problems/Wind3D/params_Wind3D_n0128_l2.txt on a single level with n^3 cells:
+    Euler + 1 tracer, FVS, FKJ98 eta 0.15, cooling 8 (mp_only_cooling), T in [5e3, 1e8],
+    reflecting / one-way-outflow, a stellar wind at the origin.
+    Returns (cfg, P, wind=(idx, states), first_step_dt_limit)."""
+    L = 3.160064e18
+    bcs = ["reflecting", "one-way-outflow"] * 3
+    cfg = abi.make_config(3, [n, n, n], abi.EQEUL, abi.FLUX_FVS, ntracer=1, artvisc=abi.AV_FKJ98_1D, etav=0.15,
+                          gamma=1.6666666666666667, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(L, L, L), bcs=bcs,
+                          refvec=[1.0e-24, 1.0e-13, 1.0e6, 1.0e6, 1.0e6, 1.0], min_temp=5.0e3, max_temp=1.0e8,
+                          cooling=abi.COOL_WSS09_CIE_LINE_HEAT_COOL, mp_timestep_limit=1, strict_fp=strict_fp)
+    P = alloc(cfg)
+    P[abi.RO] = 2.124229813e-24
+    P[abi.PG] = 2.209037632e-12
+    # keep the wind region resolved like the shipped set-up (12 cells at 128^3 on the finest of 2 levels)
+    radius = 1.543e17 * max(1.0, 256.0 / n) if n < 256 else 1.543e17
+    idx, st = wind_cells(cfg, (0.0, 0.0, 0.0), radius, 1.0e-7, 1500.0, 3.0e4, 6.96e11, [1.0])
+    for v in range(cfg.nvar):
+        P[v].reshape(-1)[idx] = st[:, v]
+    dt_lim = 0.1 * cfg.cfl * cfg.dx / (1500.0 * 1.0e5)   # calc_timestep.cpp:319-323
+    return cfg, P, (idx, st), dt_lim
+
+
 def random_states(rng, n, eqntype, ntracer=0, kind="mixed"):
     """n physically admissible primitive state pairs (left, right) for interface-flux tests,
     including degenerate cases (equal states, Bx=0, B_t=0, supersonic either way)."""

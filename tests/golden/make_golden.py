@@ -82,7 +82,21 @@ def main():
             out[name + "_dt"] = np.array(dts)
             out[name + "_P"] = r.download(0)
     np.savez_compressed(os.path.join(HERE, "steps.npz"), **out)
-    for f in ("flux_kat.npz", "cell_kat.npz", "steps.npz"):
+    # ---- Cash-Karp integrator KAT: the REFERENCE's Integrator_Base (microphysics/integrator.cpp)
+    # integrating dE/dt = f(E), f piecewise linear (see gc.ode_table)
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libpion_ref.so"))
+    xs, ys = gc.ode_table()
+    E0, dts = gc.ode_inputs(rng)
+    n = E0.size
+    Eout, tout = np.zeros(n), np.zeros(n)
+    errs = np.zeros(n, dtype=np.int32)
+    dp = C.POINTER(C.c_double)
+    lib.ref_integrate(C.c_int(xs.size), xs.ctypes.data_as(dp), ys.ctypes.data_as(dp), C.c_int(n),
+                      E0.ctypes.data_as(dp), dts.ctypes.data_as(dp), C.c_double(1.0e-2),
+                      Eout.ctypes.data_as(dp), tout.ctypes.data_as(dp), errs.ctypes.data_as(C.POINTER(C.c_int)))
+    np.savez_compressed(os.path.join(HERE, "ode_kat.npz"), E0=E0, dt=dts, Eout=Eout, tout=tout, errs=errs)
+    for f in ("flux_kat.npz", "cell_kat.npz", "steps.npz", "ode_kat.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -90,3 +90,46 @@ def step_case(name, strict_fp=1):
         cfg.sp_ooa = cfg.tm_ooa = 1
         return cfg, P
     raise KeyError(name)
+
+
+# ---- cooling ODE known-answer test -------------------------------------------------------------
+ODE_TMIN, ODE_TMAX, ODE_NT = 1.0e2, 1.0e8, 200
+ODE_GAMMA = 5.0 / 3.0
+ODE_MU_TOT_OVER_KB = 0.609 * 1.672621898e-24 / 1.38064852e-16
+ODE_MU = 1.40 * 1.672621898e-24
+ODE_RHO = ODE_MU          # rho^2 * inv_Mu2 = 1
+
+
+def ode_cie(T):
+    """a smooth positive 'cooling curve' with a peak, tabulated on the log-T grid"""
+    lt = np.log10(T)
+    return 1.0e-22 * (0.05 + np.exp(-0.5 * ((lt - 5.2) / 0.6) ** 2)) * (T / 1.0e5) ** 0.3 * 1e-2
+
+
+def ode_grid():
+    dlog = (np.log10(ODE_TMAX) - np.log10(ODE_TMIN)) / (ODE_NT - 1)
+    return np.array([10.0 ** (np.log10(ODE_TMIN) + i * dlog) for i in range(ODE_NT)])
+
+
+def ode_table():
+    """(E grid, dE/dt) equivalent to the oracle's Edot with only C_cie set: dE/dt = -C_cie(T(E))."""
+    T = ode_grid()
+    E = T * ODE_RHO / ((ODE_GAMMA - 1.0) * ODE_MU_TOT_OVER_KB)
+    return np.ascontiguousarray(E), np.ascontiguousarray(-ode_cie(T))
+
+
+def ode_cooling_tables():
+    T = ode_grid()
+    tabs = np.zeros((5, ODE_NT))
+    tabs[4] = ode_cie(T)
+    slopes = np.zeros((5, ODE_NT))
+    slopes[4, :-1] = (tabs[4, 1:] - tabs[4, :-1]) / (T[1:] - T[:-1])
+    return T, tabs, slopes
+
+
+def ode_inputs(rng, n=300):
+    T0 = 10.0 ** rng.uniform(2.5, 7.5, n)
+    E0 = T0 * ODE_RHO / ((ODE_GAMMA - 1.0) * ODE_MU_TOT_OVER_KB)
+    tcool = E0 / ode_cie(T0)
+    dts = tcool * 10.0 ** rng.uniform(-4, 0.7, n)
+    return np.ascontiguousarray(E0), np.ascontiguousarray(dts)
