@@ -1,0 +1,140 @@
+// sim_control_gpu.cpp -- see sim_control_gpu.h
+#include "sim_control_gpu.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace pion_host {
+
+sim_control_gpu::sim_control_gpu(const pion_gpu_config &c, int device) : cfg(c), h_(nullptr)
+{
+  const int rc = pion_gpu_create(&cfg, device, &h_);
+  if (rc != 0) {
+    std::string m = h_ ? last_error() : std::string("invalid configuration");
+    if (h_) pion_gpu_destroy(h_);
+    h_ = nullptr;
+    throw std::runtime_error("pion_gpu_create failed (" + std::to_string(rc) + "): " + m);
+  }
+}
+sim_control_gpu::~sim_control_gpu()
+{
+  if (h_) pion_gpu_destroy(h_);
+}
+std::string sim_control_gpu::last_error() const
+{
+  char buf[512] = {0};
+  pion_gpu_last_error(h_, buf, sizeof buf);
+  return buf;
+}
+
+int sim_control_gpu::Init(const double *P_soa, double simtime)
+{
+  T.simtime = simtime;
+  int err = pion_gpu_upload(h_, P_soa);
+  // assign_boundary_data + TimeUpdateInternalBCs/ExternalBCs (sim_init.cpp:246-267)
+  err += pion_gpu_update_bcs(h_, T.simtime, cfg.tm_ooa, cfg.tm_ooa, 1);
+  return err;
+}
+
+int sim_control_gpu::calculate_timestep()
+{
+  double t_dyn = 0.0, t_mp = 0.0;
+  int err = pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
+  if (err) return err;
+  if (T.timestep == 0 && T.first_step_dt_limit > 0.0) t_dyn = std::min(t_dyn, T.first_step_dt_limit);
+  T.dt = std::min(t_dyn, t_mp);
+  // Set_GLM_Speeds(td, dx, 0.25/dx) with the *dynamical* step (calc_timestep.cpp:119-131)
+  if (cfg.eqntype == PION_EQGLM) err += pion_gpu_set_glm_speeds(h_, t_dyn, cfg.dx, 0.25 / cfg.dx);
+  // timestep_checking_and_limiting (calc_timestep.cpp:219-262)
+  if (T.dt < T.min_timestep) throw std::runtime_error("Timestep too short!");
+  T.dt = std::min(T.dt, 1.3 * T.last_dt);  // TIMESTEP_LIMITING
+  T.dt = std::min(T.dt, T.finishtime - T.simtime);
+  if (T.dt <= 0.0) throw std::runtime_error("Negative timestep!");
+  return err;
+}
+
+int sim_control_gpu::first_order_update(double dt, int ooa)
+{
+  // Setdt, calc_microphysics_dU, calc_dynamics_dU(OA1), grid_update_state_vector(dt, OA1, ooa)
+  return pion_gpu_stage(h_, dt, 1, ooa == 1 ? 1 : 0);
+}
+int sim_control_gpu::second_order_update(double dt, int)
+{
+  return pion_gpu_stage(h_, dt, 2, 1);
+}
+
+double sim_control_gpu::advance_time()
+{
+  int err = 0;
+  if (cfg.tm_ooa == 1 && cfg.sp_ooa == 1) {
+    err += first_order_update(T.dt, cfg.tm_ooa);
+    err += pion_gpu_update_bcs(h_, T.simtime, 1, 1, 0);
+  }
+  else if (cfg.tm_ooa == 2 && cfg.sp_ooa == 2) {
+    err += first_order_update(0.5 * T.dt, 2);
+    err += pion_gpu_update_bcs(h_, T.simtime, 1, 2, 0);
+    err += second_order_update(T.dt, 2);
+    err += pion_gpu_update_bcs(h_, T.simtime, 2, 2, 0);
+  }
+  else throw std::runtime_error("Bad OOA requests; choose (1,1) or (2,2)");
+  if (err) throw std::runtime_error("advance_time: " + last_error());
+  T.simtime += T.dt;
+  T.last_dt = T.dt;
+  T.timestep++;
+  return T.dt;
+}
+
+int sim_control_gpu::Time_Int(int nsteps)
+{
+  int n = 0;
+  while (T.simtime < T.finishtime && (nsteps < 0 || n < nsteps)) {
+    int err = calculate_timestep();
+    if (err) throw std::runtime_error("calculate_timestep: " + last_error());
+    advance_time();
+    n++;
+  }
+  return n;
+}
+
+}  // namespace pion_host
+
+// ---- C view of the adapter (used by tests/bench through ctypes) -------------------------------
+extern "C" {
+int pion_host_sim_create(const pion_gpu_config *cfg, int device, void **sim)
+{
+  try {
+    *sim = new pion_host::sim_control_gpu(*cfg, device);
+    return 0;
+  }
+  catch (const std::exception &) {
+    *sim = nullptr;
+    return PION_GPU_EDEVICE;
+  }
+}
+void pion_host_sim_destroy(void *s) { delete static_cast<pion_host::sim_control_gpu *>(s); }
+void *pion_host_sim_handle(void *s) { return static_cast<pion_host::sim_control_gpu *>(s)->handle(); }
+int pion_host_sim_init(void *s, const double *P, double simtime, double finishtime, double first_dt_limit)
+{
+  auto *c = static_cast<pion_host::sim_control_gpu *>(s);
+  c->T.finishtime = finishtime;
+  c->T.first_step_dt_limit = first_dt_limit;
+  return c->Init(P, simtime);
+}
+int pion_host_sim_time_int(void *s, int nsteps, double *simtime, double *last_dt)
+{
+  auto *c = static_cast<pion_host::sim_control_gpu *>(s);
+  try {
+    int n = c->Time_Int(nsteps);
+    *simtime = c->T.simtime;
+    *last_dt = c->T.last_dt;
+    return n;
+  }
+  catch (const std::exception &) {
+    return -1;
+  }
+}
+int pion_host_sim_download(void *s, int which, double *P)
+{
+  return static_cast<pion_host::sim_control_gpu *>(s)->download(which, P);
+}
+}

@@ -1,0 +1,41 @@
+"""The C++ host adapter (pion_amd/host/sim_control_gpu.cpp: Time_Int / calculate_timestep /
+advance_time mirror) must give exactly what the Python driver gives."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from pion_amd import abi, driver, problems
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_time_int_equals_python_driver():
+    from pion_amd import lib
+    host = C.CDLL(os.path.join(ROOT, "pion_amd", "host", "libpion_host.so"))
+    dp = C.POINTER(C.c_double)
+    host.pion_host_sim_create.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.POINTER(C.c_void_p)]
+    host.pion_host_sim_init.argtypes = [C.c_void_p, dp, C.c_double, C.c_double, C.c_double]
+    host.pion_host_sim_time_int.argtypes = [C.c_void_p, C.c_int, dp, dp]
+    host.pion_host_sim_download.argtypes = [C.c_void_p, C.c_int, dp]
+    host.pion_host_sim_destroy.argtypes = [C.c_void_p]
+    host.pion_host_sim_destroy.restype = None
+    for cfg, P in (problems.mhd_blastwave(20, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1),
+                   problems.hd_blast_octant(20, 3, solver=abi.FLUX_RSroe, strict_fp=1, nzones=3.0)):
+        s = C.c_void_p()
+        assert host.pion_host_sim_create(C.byref(cfg), 0, C.byref(s)) == 0
+        Pc = np.ascontiguousarray(P).reshape(-1)
+        assert host.pion_host_sim_init(s, Pc.ctypes.data_as(dp), 0.0, 1e300, -1.0) == 0
+        t, ldt = C.c_double(), C.c_double()
+        assert host.pion_host_sim_time_int(s, 4, C.byref(t), C.byref(ldt)) == 4
+        out = np.empty_like(Pc)
+        assert host.pion_host_sim_download(s, 0, out.ctypes.data_as(dp)) == 0
+        host.pion_host_sim_destroy(s)
+        with lib.GpuSim(cfg, 0) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            sc.time_int(4)
+            assert sc.simtime == t.value and sc.last_dt == ldt.value
+            assert np.array_equal(g.download(0).reshape(-1), out)
