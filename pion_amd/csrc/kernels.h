@@ -50,8 +50,9 @@ struct StageArgs {
   double dt;          // stage dt (= FV_dt)
   double glm_damp;    // exp(-FV_dt*chyp*cr), evaluated on the host
   double max_temp;    // EP.MaxTemperature
-  int use_march;      // 1: k_stage_march (3-D, nbc>=2), 0: k_stage (cell per thread)
-  int zchunk;         // planes per wavefront in k_stage_march
+  int use_march;      // 2: k_stage_rows, 1: k_stage_march (3-D, nbc>=2), 0: k_stage (cell per thread)
+  int zchunk;         // planes per wavefront in the marching kernels
+  int rows;           // y-rows per wavefront in k_stage_rows
   CoolDev cool;
 };
 

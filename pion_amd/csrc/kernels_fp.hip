@@ -51,8 +51,14 @@ PDEV int rotvar(const int ax, const int s)
 PDEV double avg_falle(const double a, const double b)
 {
   if (a * b <= PION_VERY_TINY_VALUE) return 0.0;
+#ifdef PION_FAST_MATH
+  // a and b have the same sign here, so r = a/b > 0 and min(r,1)*b is a (if |a|<|b|) or b:
+  // the fast build picks it without the division (differs from the reference form by <= 1 ulp)
+  return (fabs(a) < fabs(b)) ? a : b;
+#else
   double r = a / b;
   return (r > 0.0) ? dmin(r, 1.0) * b : 0.0;
+#endif
 }
 // XCD-aware tile decode: workgroups are dealt round-robin to the 8 XCDs (b % 8 share an XCD);
 // give each XCD a contiguous range of tiles so that the halo re-reads of neighbouring tiles hit
@@ -345,11 +351,13 @@ __global__ __launch_bounds__(256) void k_flux_test(const FluxTestArgs a)
 }
 
 #include "stage_march.h"
+#include "stage_rows.h"
 
 template <int EQ, int NTR, int SOLVER>
 static int stage_go(const StageArgs &a, hipStream_t s)
 {
-  if (a.use_march && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_march_go<EQ, NTR, SOLVER>(a, s);
+  if (a.use_march == 2 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_rows_go<EQ, NTR, SOLVER>(a, s);
+  if (a.use_march == 1 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_march_go<EQ, NTR, SOLVER>(a, s);
   const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
   const long ntiles = (long)nbx * nby * a.g.ng[2];
   const long nblocks = ((ntiles + 7) / 8) * 8;

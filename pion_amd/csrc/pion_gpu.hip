@@ -203,7 +203,7 @@ struct Handle {
   bool timing = false;
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
-  int use_march = 1, zchunk = 32;
+  int use_march = 2, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
 };
 
 #define HCHECK(h, call)                                                            \
@@ -289,8 +289,10 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
 
   Handle *h = new Handle;
   h->cfg = *cfg;
-  if (const char *e = getenv("PION_STAGE_KERNEL")) h->use_march = (strcmp(e, "cell") != 0);
-  if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 32;
+  if (const char *e = getenv("PION_STAGE_KERNEL"))
+    h->use_march = (strcmp(e, "cell") == 0) ? 0 : ((strcmp(e, "march") == 0) ? 1 : 2);
+  if (const char *e = getenv("PION_ROWS")) h->rows = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
+  if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 0;
   h->device = device;
   if (hipSetDevice(device) != hipSuccess) {
     delete h;
@@ -317,8 +319,8 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   HCHECK(h, hipMemset(h->dP, 0, nb));
   HCHECK(h, hipMemset(h->dPh, 0, nb));
   HCHECK(h, hipMalloc(&h->dflags, g.ncell));
-  HCHECK(h, hipMalloc(&h->derr, sizeof(int)));
-  HCHECK(h, hipMemset(h->derr, 0, sizeof(int)));
+  HCHECK(h, hipMalloc(&h->derr, 64));
+  HCHECK(h, hipMemset(h->derr, 0, 64));
   HCHECK(h, hipMalloc(&h->ddt, 2 * sizeof(unsigned long long)));
   if (cfg->eqntype != PION_EQEUL && cfg->solver == PION_FLUX_RS_HLLD) {
     HCHECK(h, hipMalloc(&h->dhll, g.ncell));
@@ -481,6 +483,7 @@ int pion_gpu_synchronize(void *handle)
 {
   Handle *h = (Handle *)handle;
   HCHECK(h, hipStreamSynchronize(h->stream));
+
   return 0;
 }
 
@@ -726,7 +729,15 @@ int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_ste
   a.max_temp = cfg.max_temp;
   a.cool = h->cool;
   a.use_march = h->use_march;
+  a.rows = h->rows;
   a.zchunk = h->zchunk;
+  if (a.zchunk <= 0) {
+    // planes per wavefront: long chunks amortise the priming plane, but keep >= ~4 wavefronts per SIMD
+    // (1024 SIMDs) in flight so that the tail of the launch stays short
+    const long per_plane_chunk = (long)((h->g.ng[0] + 61) / 62) * ((h->g.ng[1] + a.rows - 1) / a.rows);
+    a.zchunk = 64;
+    while (a.zchunk > 8 && per_plane_chunk * ((h->g.ng[2] + a.zchunk - 1) / a.zchunk) < 4096) a.zchunk /= 2;
+  }
   time_begin(h, 0);
   rc = cfg.strict_fp ? fp_strict::launch_stage(a, h->stream) : fp_fast::launch_stage(a, h->stream);
   time_end(h, 0);

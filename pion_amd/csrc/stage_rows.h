@@ -1,0 +1,334 @@
+// stage_rows.h -- k_stage_rows: the 3-D production stage kernel.
+//
+// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after stage_march.h, whose helpers
+// load_rot / slope3 / apply_axis / cell_update_store it reuses).
+//
+// Same dataflow as k_stage_march (one wavefront per x-pencil of 64 cells, 62 outputs, marching
+// along z, x fluxes shared by wavefront shuffles) with two changes aimed at what the profile of
+// k_stage_march showed (fp64 VALU-bound, 4 Riemann solves per cell, 1 wave/SIMD, 28 % of the wave
+// time parked on memory):
+//   * a wavefront owns R consecutive y-rows and visits them one after the other inside each
+//     z-plane, carrying the flux through the upper y face (and the slope of the next row) to the
+//     next row in registers: (3R+1)/R Riemann solves and (3R+2)/R.. slopes per cell instead of 4 / 5;
+//   * the z-carried state (slope of the current plane, flux through the lower z face) of every
+//     row lives in LDS ([row][var][lane], conflict-free 8-byte accesses), not in registers, so the
+//     kernel fits 256 VGPRs and two wavefronts share a SIMD to cover memory latency.
+// The arithmetic and its order are unchanged (strict build stays bit-identical to the oracle).
+#ifndef PION_STAGE_ROWS_H
+#define PION_STAGE_ROWS_H
+
+template <int EQ, int NTR, int SOLVER>
+__global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
+{
+  typedef Eqn<EQ, NTR> E;
+  typedef Flux<EQ, NTR, SOLVER> FX;
+  constexpr int NV = E::NV;
+  constexpr bool MHD = E::MHD;
+  extern __shared__ double lds[];
+
+  const int R = a.rows;
+  const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
+  const int nyg = (a.g.ng[1] + R - 1) / R;
+  const int nzc = (a.g.ng[2] + a.zchunk - 1) / a.zchunk;
+  const long ntiles = (long)ntx * nyg * nzc;
+  const int wave = threadIdx.x >> 6;
+  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
+  if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
+  const int tx = (int)(tile % ntx), jg = (int)((tile / ntx) % nyg), cz = (int)(tile / ((long)ntx * nyg));
+  const int lane = threadIdx.x & 63;
+  int ix = tx * PION_MARCH_XT - 1 + lane;
+  const bool writer = (lane >= 1 && lane <= PION_MARCH_XT && ix < a.g.ng[0]);
+  if (ix > a.g.ng[0]) ix = a.g.ng[0];
+  const int j0 = jg * R;
+  const int nrows = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
+  const int k0 = cz * a.zchunk;
+  const int k1 = (k0 + a.zchunk < a.g.ng[2]) ? k0 + a.zchunk : a.g.ng[2];
+
+  const long nc = a.g.ncell, sy = a.g.sy, sz = a.g.sz;
+  const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
+  const bool oa2 = (a.space_ooa == 2);
+  const bool hcorr = (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
+  int err = 0;
+
+  // this wavefront's LDS: zst[row][slot][lane], slot 0..NV-1 = z slope, NV..2NV-1 = lower z flux
+  const int zbase = wave * R * (2 * NV) * 64 + lane;
+#define ZS(r, s) lds[zbase + ((r) * (2 * NV) + (s)) * 64]
+
+  const long crow0 = (long)(ix + a.g.nbc[0]) + sy * (j0 + a.g.nbc[1]) + sz * (k0 - 1 + a.g.nbc[2]);
+
+  // z slope of the priming plane k0-1 for every row
+#pragma unroll 1
+  for (int r = 0; r < nrows; r++) {
+    const long c = crow0 + sy * r;
+    double qa[NV], qb[NV], qc[NV], s[NV];
+    load_rot<NV, MHD>(a.S, nc, 2, c - sz, qa);
+    load_rot<NV, MHD>(a.S, nc, 2, c, qb);
+    load_rot<NV, MHD>(a.S, nc, 2, c + sz, qc);
+    slope3<NV>(qa, qb, qc, dx, oa2, s);
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      ZS(r, v) = s[v];
+      ZS(r, NV + v) = 0.0;
+    }
+  }
+
+#pragma unroll 1
+  for (int k = k0 - 1; k < k1; k++) {
+    const bool prime = (k == k0 - 1);
+    // carried from row to row inside this plane (y sweep frame)
+    double Fy[NV], ysn[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) Fy[v] = ysn[v] = 0.0;
+
+#pragma unroll 1
+    for (int r = 0; r < nrows; r++) {
+      const long c = crow0 + sy * r + sz * (k - (k0 - 1));
+      double q0[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) q0[v] = a.S[v * nc + c];
+      double dU[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) dU[v] = 0.0;
+      // start-of-step state and flags of this cell: issued now, consumed after the four tasks
+      double P0[NV];
+      uint8_t fl = 0;
+      if (!prime) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
+        fl = a.flags[c];
+      }
+
+      if (!prime && a.cooling != 0) {
+        if (fl & 4) {
+          // calc_noRT_microphysics_dU (time_integrator.cpp:438-489)
+          double pn[NV], ui[NV], uf[NV];
+#pragma unroll
+          for (int v = 0; v < NV; v++) pn[v] = P0[v];
+          pn[qPG] = Cooling::time_update(a.cool, P0[qRO], P0[qPG], dt, g, err);
+          E::PtoU(P0, ui, g);
+          E::PtoU(pn, uf, g);
+#pragma unroll
+          for (int v = 0; v < NV; v++) dU[v] += uf[v] - ui[v];
+        }
+      }
+
+      double ys0[NV];  // y slope of this row (kept between the two y tasks)
+      double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;
+
+#pragma unroll 1
+      for (int t = prime ? 3 : 0; t < 4; t++) {
+        if (t == 1 && r > 0) continue;  // lower y face: flux carried from the previous row
+        double eL[NV], eR[NV], f[NV], pstar[NV];
+        long cl, st;
+        int ax;
+        if (t == 0) {
+          ax = 0;
+          st = 1;
+          cl = c;
+          double qm[NV], qp[NV], sx[NV];
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            qm[v] = a.S[v * nc + c - 1];
+            qp[v] = a.S[v * nc + c + 1];
+          }
+          slope3<NV>(qm, q0, qp, dx, oa2, sx);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            double em;
+            if (oa2) {
+              eL[v] = q0[v] + sx[v] * dx * 0.5;
+              em = q0[v] - sx[v] * dx * 0.5;
+            }
+            else {
+              eL[v] = q0[v];
+              em = q0[v];
+            }
+            eR[v] = __shfl_down(em, 1, 64);
+          }
+          if constexpr (MHD) {
+            bnm = qm[qBN];
+            bnp = qp[qBN];
+            if constexpr (EQ == EQGLM) {
+              sim = qm[qSI];
+              sip = qp[qSI];
+            }
+          }
+        }
+        else if (t == 1) {
+          // first row of the group: lower y face (c-sy | c); slopes of rows j-1, j (j+1 follows in t==2)
+          ax = 1;
+          st = sy;
+          cl = c - sy;
+          double qm2[NV], qm1[NV], qp1[NV], yq0[NV], sm1[NV];
+          load_rot<NV, MHD>(a.S, nc, 1, c - sy, qm1);
+          load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
+          to_sweep<NV, MHD>(1, q0, yq0);
+          if (oa2) load_rot<NV, MHD>(a.S, nc, 1, c - 2 * sy, qm2);
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qm2[v] = 0.0;
+          }
+          slope3<NV>(qm2, qm1, yq0, dx, oa2, sm1);
+          slope3<NV>(qm1, yq0, qp1, dx, oa2, ys0);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            if (oa2) {
+              eL[v] = qm1[v] + sm1[v] * dx * 0.5;
+              eR[v] = yq0[v] - ys0[v] * dx * 0.5;
+            }
+            else {
+              eL[v] = qm1[v];
+              eR[v] = yq0[v];
+            }
+          }
+        }
+        else if (t == 2) {
+          // upper y face (c | c+sy): slope of the next row is new, this row's slope is ys0 / carried
+          ax = 1;
+          st = sy;
+          cl = c;
+          double yq0[NV], qp1[NV], qp2[NV], sp[NV];
+          to_sweep<NV, MHD>(1, q0, yq0);
+          load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
+          if (oa2) load_rot<NV, MHD>(a.S, nc, 1, c + 2 * sy, qp2);
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp2[v] = 0.0;
+          }
+          if (r > 0) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) ys0[v] = ysn[v];
+          }
+          slope3<NV>(yq0, qp1, qp2, dx, oa2, sp);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            if (oa2) {
+              eL[v] = yq0[v] + ys0[v] * dx * 0.5;
+              eR[v] = qp1[v] - sp[v] * dx * 0.5;
+            }
+            else {
+              eL[v] = yq0[v];
+              eR[v] = qp1[v];
+            }
+            ysn[v] = sp[v];
+          }
+          if constexpr (MHD) {
+            bnp = qp1[qBN];
+            bnm = a.S[(long)rotvar<MHD>(1, qBN) * nc + c - sy];
+            if constexpr (EQ == EQGLM) {
+              sip = qp1[qSI];
+              sim = a.S[(long)qSI * nc + c - sy];
+            }
+          }
+        }
+        else {
+          // upper z face (c | c+sz)
+          ax = 2;
+          st = sz;
+          cl = c;
+          double zq0[NV], qp1[NV], qp2[NV], sn[NV];
+          to_sweep<NV, MHD>(2, q0, zq0);
+          load_rot<NV, MHD>(a.S, nc, 2, c + sz, qp1);
+          if (oa2) load_rot<NV, MHD>(a.S, nc, 2, c + 2 * sz, qp2);
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp2[v] = 0.0;
+          }
+          slope3<NV>(zq0, qp1, qp2, dx, oa2, sn);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            const double sc = ZS(r, v);
+            if (oa2) {
+              eL[v] = zq0[v] + sc * dx * 0.5;
+              eR[v] = qp1[v] - sn[v] * dx * 0.5;
+            }
+            else {
+              eL[v] = zq0[v];
+              eR[v] = qp1[v];
+            }
+            ZS(r, v) = sn[v];
+          }
+          if constexpr (MHD) {
+            bnp = qp1[qBN];
+            bnm = a.S[(long)rotvar<MHD>(2, qBN) * nc + c - sz];
+            if constexpr (EQ == EQGLM) {
+              sip = qp1[qSI];
+              sim = a.S[(long)qSI * nc + c - sz];
+            }
+          }
+        }
+
+        double hc_eta = 0.0;
+        if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
+        bool use_hll = false;
+        if constexpr (MHD && SOLVER == FLUX_RS_HLLD) use_hll = (a.hllflag[cl] | a.hllflag[cl + st]) != 0;
+        FX::intercell_flux(eL, eR, f, pstar, a.fc, hc_eta, use_hll, err);
+
+        if (t == 0) {
+          double Fm[NV];
+#pragma unroll
+          for (int v = 0; v < NV; v++) Fm[v] = __shfl_up(f[v], 1, 64);
+          apply_axis<EQ, NV>(dU, q0, bnm, sim, bnp, sip, Fm, f, dt, dx);
+        }
+        else if (t == 1) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) Fy[v] = f[v];
+        }
+        else if (t == 2) {
+          double d[NV], yq0[NV];
+          to_sweep<NV, MHD>(1, q0, yq0);
+          to_sweep<NV, MHD>(1, dU, d);
+          apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
+          from_sweep<NV, MHD>(1, d, dU);
+#pragma unroll
+          for (int v = 0; v < NV; v++) Fy[v] = f[v];  // lower-face flux of the next row
+        }
+        else {
+          if (!prime) {
+            double d[NV], zq0[NV], Fzl[NV];
+            to_sweep<NV, MHD>(2, q0, zq0);
+            to_sweep<NV, MHD>(2, dU, d);
+#pragma unroll
+            for (int v = 0; v < NV; v++) Fzl[v] = ZS(r, NV + v);
+            apply_axis<EQ, NV>(d, zq0, bnm, sim, bnp, sip, Fzl, f, dt, dx);
+            from_sweep<NV, MHD>(2, d, dU);
+          }
+#pragma unroll
+          for (int v = 0; v < NV; v++) ZS(r, NV + v) = f[v];
+        }
+      }
+
+      if (!prime && writer) {
+        if (!(fl & 4) || !(fl & 16)) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) a.out[v * nc + c] = P0[v];
+        }
+        else cell_update_store<EQ, NTR>(a, c, P0, dU, err);
+      }
+    }
+  }
+#undef ZS
+  if (err) atomicOr(a.errword, err);
+}
+
+template <int EQ, int NTR, int SOLVER>
+static int stage_rows_go(const StageArgs &a0, hipStream_t s)
+{
+  constexpr int NV = Eqn<EQ, NTR>::NV;
+  // rows per wavefront limited by the 160 KiB of LDS a 4-wave workgroup may hold
+  StageArgs a = a0;
+  const int rmax = (int)((160 * 1024) / (sizeof(double) * 4 * (2 * NV) * 64));
+  if (a.rows > rmax) a.rows = rmax;
+  if (a.rows < 1) a.rows = 1;
+  const int R = a.rows;
+  const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
+  const int nyg = (a.g.ng[1] + R - 1) / R;
+  const int nzc = (a.g.ng[2] + a.zchunk - 1) / a.zchunk;
+  const long ntiles = (long)ntx * nyg * nzc;
+  const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
+  const size_t shmem = sizeof(double) * 4 * R * (2 * NV) * 64;
+  hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+  return (int)hipGetLastError();
+}
+
+#endif

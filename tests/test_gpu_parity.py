@@ -138,3 +138,41 @@ def test_interface_flux_strict(eq, solvers):
                         else:
                             assert np.array_equal(Fg, Fo, equal_nan=True), (eq, sv, ntr, av, ax,
                                                                              np.nanmax(np.abs(Fg - Fo)))
+
+
+def _with_tracers(cfg0, P0, ntr):
+    """same problem with ntr extra passive tracers (blast region = 1)"""
+    base = cfg0.nvar - cfg0.ntracer
+    bcs = [cfg0.bc_type[d] for d in range(2 * cfg0.ndim)]
+    cfg = abi.make_config(cfg0.ndim, [cfg0.ng[a] for a in range(cfg0.ndim)], cfg0.eqntype, cfg0.solver, ntracer=ntr,
+                          artvisc=cfg0.artvisc, etav=cfg0.etav, gamma=cfg0.gamma, cfl=cfg0.cfl, dx=cfg0.dx,
+                          xmin=tuple(cfg0.xmin), bcs=bcs, refvec=[cfg0.refvec[v] for v in range(base)] + [1.0] * ntr,
+                          strict_fp=cfg0.strict_fp)
+    P = np.zeros((cfg.nvar,) + P0.shape[1:])
+    P[:base] = P0[:base]
+    hot = P0[abi.PG] > 2.0 * P0[abi.PG].min()
+    for t in range(ntr):
+        P[base + t] = np.where(hot, 1.0 - 0.25 * t, 0.1 * t)
+    return cfg, P
+
+
+@pytest.mark.parametrize("ntr", [0, 1, 2])
+@pytest.mark.parametrize("solver", [0, 1, 2, 3, 4, 5, 6, 8])
+def test_every_hd_instantiation_3d(solver, ntr):
+    """every (solver, ntracer) template instance of the 3-D stage kernel (a miscompile of single
+    instances was seen with -O3 / SLP, see csrc/Makefile)"""
+    cfg0, P0 = problems.hd_blast_octant(14, 3, solver=solver, strict_fp=1, nzones=3.0)
+    cfg, P = _with_tracers(cfg0, P0, ntr)
+    if solver in (1, 2, 3):
+        run_pair(cfg, P, 2, strict=False, tol=1e-9)
+    else:
+        run_pair(cfg, P, 2)
+
+
+@pytest.mark.parametrize("ntr", [0, 1, 2])
+@pytest.mark.parametrize("solver", [0, 7, 8])
+@pytest.mark.parametrize("eq", [abi.EQMHD, abi.EQGLM])
+def test_every_mhd_instantiation_3d(eq, solver, ntr):
+    cfg0, P0 = problems.mhd_blastwave(14, 3, eq, solver, strict_fp=1)
+    cfg, P = _with_tracers(cfg0, P0, ntr)
+    run_pair(cfg, P, 2)
