@@ -144,6 +144,10 @@ int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh);
 void *pion_gpu_device_ptr(void *handle, int which);
 /* HIP stream all subsequent work of this handle is issued on (hipStream_t) */
 int pion_gpu_set_stream(void *handle, void *stream);
+/* Second HIP stream for pion_gpu_pack_halo / pion_gpu_unpack_halo (NULL: the compute stream).
+ * The library orders pack after the compute stream's work so far and PION_STAGE_ZBOUNDARY after the
+ * last unpack; the caller's transfer (RCCL/MPI) must be enqueued on, or ordered with, this stream. */
+int pion_gpu_set_comm_stream(void *handle, void *stream);
 int pion_gpu_synchronize(void *handle);
 
 /* internal fixed-state cells: stellar wind (grid/stellar_wind_BC.cpp:642-677,
@@ -186,6 +190,20 @@ int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr);
  * space_ooa: OA1 (first half step) or OA2; is_full_step: step==ooa (P=Ph). */
 int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_step);
 
+/* The same stage in two parts, so that a z-slab's halo exchange (MCMD_boundaries.cpp:122-237, which
+ * the reference completes before calc_dynamics_dU starts) runs underneath most of the work:
+ *   PION_STAGE_INTERIOR   the on-grid planes that read no z ghost plane; may be issued while the
+ *                         z halo of the stencil array is still in flight;
+ *   PION_STAGE_ZBOUNDARY  the nbc planes next to each z face; ordered after the last
+ *                         pion_gpu_unpack_halo (comm stream) inside the library.
+ * INTERIOR followed by ZBOUNDARY gives bit for bit the result of PION_STAGE_WHOLE (= pion_gpu_stage).
+ * Configurations the split does not cover (1-D/2-D, H-correction, first-order scheme, <= 2*nbc
+ * planes) do all the work in the ZBOUNDARY call. */
+#define PION_STAGE_WHOLE 0
+#define PION_STAGE_INTERIOR 1
+#define PION_STAGE_ZBOUNDARY 2
+int pion_gpu_stage_part(void *handle, double dt_stage, int space_ooa, int is_full_step, int part);
+
 /* time_integrator::advance_time (time_integrator.cpp:72-142) for OA1/OA1 and
  * OA2/OA2: stages + boundary updates. */
 int pion_gpu_advance_time(void *handle, double dt, double simtime);
@@ -216,7 +234,8 @@ int pion_gpu_cooling_update(void *handle, int n, double dt, const double *P_in, 
 int pion_gpu_cooling_edot(void *handle, int n, const double *rho, const double *T, double *edot);
 
 /* last kernel timings, milliseconds, measured with HIP events on the handle's stream:
- * out[0]=stage kernel, out[1]=prepass, out[2]=bc fill, out[3]=dt reduction */
+ * out[0]=stage kernel, out[1]=prepass, out[2]=bc fill, out[3]=dt reduction (mean per launch);
+ * with n >= 8 also out[4..7] = the number of launches each mean was taken over */
 int pion_gpu_enable_timing(void *handle, int on);
 int pion_gpu_get_timing(void *handle, double *out, int n);
 

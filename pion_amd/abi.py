@@ -31,6 +31,7 @@ CELL_ISGD, CELL_ISBD, CELL_ISDOMAIN, CELL_TIMESTEP, CELL_ISLEAF = 1, 2, 4, 8, 16
 RO, PG, VX, VY, VZ, BX, BY, BZ, SI = range(9)
 RHO, ERG, MMX, MMY, MMZ, BBX, BBY, BBZ, PSI = range(9)
 OA1, OA2 = 1, 2
+STAGE_WHOLE, STAGE_INTERIOR, STAGE_ZBOUNDARY = 0, 1, 2
 
 E_OK, E_INVAL, E_DEVICE, E_PHYSICS, E_NOMEM = 0, -1, -2, -3, -4
 
@@ -111,5 +112,22 @@ def ncell_all(cfg):
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def share_torch_hip_runtime():
+    """Call before dlopen-ing anything that links libamdhip64 (libpion_gpu.so, libpion_host.so).
+
+    PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Whichever HIP runtime is
+    loaded first serves the whole process: with torch first, our libraries bind to torch's copy and
+    everything shares one runtime (streams, device memory and RCCL interoperate); with our library
+    first, a later `import torch` brings a second runtime and reports "No HIP GPUs are available".
+    torch carries the multi-GPU path (pion_amd.slab), so it goes first whenever it is installed;
+    PION_NO_TORCH=1 skips this for torch-free deployments."""
+    if os.environ.get("PION_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+
 def library_path():
-    return os.path.join(_HERE, "csrc", "libpion_gpu.so")
+    # PION_GPU_LIB: an alternative build of the same library (compiler-flag A/B runs)
+    return os.environ.get("PION_GPU_LIB") or os.path.join(_HERE, "csrc", "libpion_gpu.so")

@@ -6,6 +6,8 @@ import os
 
 import numpy as np
 
+from . import abi
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
 
@@ -16,6 +18,7 @@ def _load():
         path = os.path.join(_HERE, "host", "libpion_host.so")
         if not os.path.exists(path):
             raise ImportError("%s not found: run __graft_entry__.build()" % path)
+        abi.share_torch_hip_runtime()
         _lib = C.CDLL(path)
         dp = C.POINTER(C.c_double)
         _lib.pion_host_build_cooling_tables.argtypes = [C.c_double, C.c_double, C.c_int, dp, dp, dp]

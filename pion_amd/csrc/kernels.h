@@ -53,6 +53,10 @@ struct StageArgs {
   int use_march;      // 2: k_stage_rows, 1: k_stage_march (3-D, nbc>=2), 0: k_stage (cell per thread)
   int zchunk;         // planes per wavefront in the marching kernels
   int rows;           // y-rows per wavefront in k_stage_rows
+  int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows; others: whole grid)
+  unsigned long long *dtres;  // k_stage_rows, full step: min t_dyn / t_mp bits of the new state (or null)
+  double cfl;
+  int dt_mp;          // also reduce the cooling time (EP.MP_timestep_limit)
   CoolDev cool;
 };
 
@@ -64,6 +68,7 @@ struct PrepassArgs {
   double *eta;            // [ndim][ncell]
   int eqntype, nvar, space_ooa;
   double gamma;
+  long c0, c1;            // cell range [c0,c1) (whole planes) this launch covers
 };
 
 struct DtArgs {

@@ -457,9 +457,9 @@ const char *stage_kernel_name(int, int, int) { return "k_stage"; }
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
 {
-  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long c = a.c0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nc = a.g.ncell;
-  if (c >= nc) return;
+  if (c >= a.c1) return;
   int i[3];
   i[0] = (int)(c % a.g.nga[0]);
   i[1] = (int)((c / a.g.nga[0]) % a.g.nga[1]);
@@ -488,9 +488,9 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
 template <int NVMAX>
 __global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
 {
-  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long c = a.c0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long nc = a.g.ncell;
-  if (c >= nc) return;
+  if (c >= a.c1) return;
   int i[3];
   i[0] = (int)(c % a.g.nga[0]);
   i[1] = (int)((c / a.g.nga[0]) % a.g.nga[1]);
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
 
 int launch_prepass(const PrepassArgs &a, hipStream_t s)
 {
-  const unsigned nb = (unsigned)((a.g.ncell + 255) / 256);
+  const unsigned nb = (unsigned)((a.c1 - a.c0 + 255) / 256);
   if (a.hllflag) hipLaunchKernelGGL(k_prepass_hlld, dim3(nb), dim3(256), 0, s, a);
   if (a.eta) hipLaunchKernelGGL((k_prepass_hcorr<8>), dim3(nb), dim3(256), 0, s, a);
   return (int)hipGetLastError();

@@ -177,12 +177,16 @@ struct Handle {
   GridDesc g;
   int device = 0;
   hipStream_t stream = 0;
+  hipStream_t comm_stream = 0;     // pack/unpack of the z halo (0: the compute stream)
+  hipEvent_t ev_packed_src = nullptr, ev_unpacked = nullptr;
+  bool ev_unpacked_valid = false;
   double *dP = nullptr, *dPh = nullptr;
   bool own_state = true;
   uint8_t *dflags = nullptr, *dhll = nullptr;
   double *deta = nullptr;
   int *derr = nullptr;
-  unsigned long long *ddt = nullptr;
+  unsigned long long *ddt = nullptr;   // [0]=min t_dyn, [1]=min t_mp (bit patterns)
+  unsigned long long *ddt_init = nullptr;  // {1e100, 1e99} on the device: reset source (no host buffer in flight)
   std::vector<uint8_t> hflags;
   // boundary state
   double refval[6][PION_MAX_NVAR];
@@ -198,12 +202,14 @@ struct Handle {
   double glm_chyp = 0.0, glm_cr = 0.0;
   double refvec_avg[PION_MAX_NVAR];
   bool ph_valid = false;  // dPh holds a genuine half-step state
+  bool dt_cached = false; // ddt holds the time-step minima of the current P (left by the last full stage)
   std::string err;
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
   int use_march = 2, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
+  bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
 };
 
 #define HCHECK(h, call)                                                            \
@@ -214,6 +220,17 @@ struct Handle {
       return PION_GPU_EDEVICE;                                                     \
     }                                                                              \
   } while (0)
+
+// Two-stream mode: everything on the compute stream that touches the z ghost planes must run after
+// the last unpack on the comm stream.  One wait is enough, later work is ordered behind it.
+int order_after_unpack(Handle *h)
+{
+  if (h->comm_stream && h->comm_stream != h->stream && h->ev_unpacked_valid) {
+    HCHECK(h, hipStreamWaitEvent(h->stream, h->ev_unpacked, 0));
+    h->ev_unpacked_valid = false;
+  }
+  return 0;
+}
 
 long cell_id(const GridDesc &g, int ix, int iy, int iz)
 {
@@ -291,6 +308,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   h->cfg = *cfg;
   if (const char *e = getenv("PION_STAGE_KERNEL"))
     h->use_march = (strcmp(e, "cell") == 0) ? 0 : ((strcmp(e, "march") == 0) ? 1 : 2);
+  if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_ROWS")) h->rows = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
   if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 0;
   h->device = device;
@@ -322,6 +340,11 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   HCHECK(h, hipMalloc(&h->derr, 64));
   HCHECK(h, hipMemset(h->derr, 0, 64));
   HCHECK(h, hipMalloc(&h->ddt, 2 * sizeof(unsigned long long)));
+  HCHECK(h, hipMalloc(&h->ddt_init, 2 * sizeof(unsigned long long)));
+  {
+    const double init[2] = {1.e100, 1.0e99};
+    HCHECK(h, hipMemcpy(h->ddt_init, init, sizeof init, hipMemcpyHostToDevice));
+  }
   if (cfg->eqntype != PION_EQEUL && cfg->solver == PION_FLUX_RS_HLLD) {
     HCHECK(h, hipMalloc(&h->dhll, g.ncell));
     HCHECK(h, hipMemset(h->dhll, 0, g.ncell));
@@ -412,6 +435,7 @@ void pion_gpu_destroy(void *handle)
   hipFree(h->deta);
   hipFree(h->derr);
   hipFree(h->ddt);
+  hipFree(h->ddt_init);
   hipFree(h->dwind_idx);
   hipFree(h->dwind_state);
   hipFree(h->dcoolT);
@@ -419,6 +443,8 @@ void pion_gpu_destroy(void *handle)
   hipFree(h->dcoolslope);
   for (int s = 0; s < 4; s++)
     for (hipEvent_t e : h->ev[s]) hipEventDestroy(e);
+  if (h->ev_packed_src) hipEventDestroy(h->ev_packed_src);
+  if (h->ev_unpacked) hipEventDestroy(h->ev_unpacked);
   delete h;
 }
 
@@ -441,6 +467,7 @@ int pion_gpu_upload(void *handle, const double *P_soa)
   HCHECK(h, hipMemcpyAsync(h->dPh, h->dP, nb, hipMemcpyDeviceToDevice, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   h->ph_valid = false;
+  h->dt_cached = false;
   return 0;
 }
 
@@ -450,6 +477,7 @@ int pion_gpu_download(void *handle, int which, double *P_soa)
   const size_t nb = sizeof(double) * (size_t)h->cfg.nvar * h->g.ncell;
   // after a full step the reference has Ph == P everywhere (time_integrator.cpp:938-939)
   const double *src = (which == 1 && h->ph_valid) ? h->dPh : h->dP;
+  if (int rc = order_after_unpack(h)) return rc;
   HCHECK(h, hipMemcpyAsync(P_soa, src, nb, hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   return check_errword(h);
@@ -467,11 +495,13 @@ int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh)
   h->dP = (double *)dP;
   h->dPh = (double *)dPh;
   h->ph_valid = false;
+  h->dt_cached = false;
   return 0;
 }
 void *pion_gpu_device_ptr(void *handle, int which)
 {
   Handle *h = (Handle *)handle;
+  h->dt_cached = false;  // the caller may write through the pointer
   return which == 0 ? (void *)h->dP : (void *)h->dPh;
 }
 int pion_gpu_set_stream(void *handle, void *stream)
@@ -479,11 +509,18 @@ int pion_gpu_set_stream(void *handle, void *stream)
   ((Handle *)handle)->stream = (hipStream_t)stream;
   return 0;
 }
+int pion_gpu_set_comm_stream(void *handle, void *stream)
+{
+  Handle *h = (Handle *)handle;
+  h->comm_stream = (hipStream_t)stream;
+  h->ev_unpacked_valid = false;
+  return 0;
+}
 int pion_gpu_synchronize(void *handle)
 {
   Handle *h = (Handle *)handle;
   HCHECK(h, hipStreamSynchronize(h->stream));
-
+  if (h->comm_stream && h->comm_stream != h->stream) HCHECK(h, hipStreamSynchronize(h->comm_stream));
   return 0;
 }
 
@@ -642,14 +679,16 @@ int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
     h->err = "cooling tables not set";
     return PION_GPU_EINVAL;
   }
-  double init[2] = {1.e100, 1.0e99};
-  HCHECK(h, hipMemcpyAsync(h->ddt, init, sizeof init, hipMemcpyHostToDevice, h->stream));
-  time_begin(h, 3);
-  const int rc = h->cfg.strict_fp ? fp_strict::launch_dt(a, h->stream) : fp_fast::launch_dt(a, h->stream);
-  time_end(h, 3);
-  if (rc != 0) {
-    h->err = "dt kernel launch failed";
-    return PION_GPU_EDEVICE;
+  if (!h->dt_cached) {
+    // (after a full step through k_stage_rows the minima of the new state are already in ddt)
+    HCHECK(h, hipMemcpyAsync(h->ddt, h->ddt_init, 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    time_begin(h, 3);
+    const int rc = h->cfg.strict_fp ? fp_strict::launch_dt(a, h->stream) : fp_fast::launch_dt(a, h->stream);
+    time_end(h, 3);
+    if (rc != 0) {
+      h->err = "dt kernel launch failed";
+      return PION_GPU_EDEVICE;
+    }
   }
   double out[2];
   HCHECK(h, hipMemcpyAsync(out, h->ddt, sizeof out, hipMemcpyDeviceToHost, h->stream));
@@ -667,9 +706,18 @@ int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr)
   return 0;
 }
 
-int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_step)
+// One stage, or a part of one (PION_STAGE_WHOLE / _INTERIOR / _ZBOUNDARY).  The split lets the z-halo
+// exchange of a slab run under the interior: the interior part reads no z ghost plane, the z-boundary
+// part (the nbc on-grid planes next to each z face) waits for the unpacked halo.
+static bool stage_can_split(const Handle *h)
 {
-  Handle *h = (Handle *)handle;
+  return h->use_march == 2 && h->g.ndim == 3 && h->g.nbc[2] >= 2 && !h->deta
+         && h->g.ng[2] > 2 * h->g.nbc[2] && !(h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1);
+}
+
+static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_step, int kz0, int kz1,
+                        bool first, bool last)
+{
   const pion_gpu_config &cfg = h->cfg;
   if (cfg.cooling != 0 && !h->have_tables) {
     h->err = "cooling tables not set";
@@ -691,6 +739,24 @@ int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_ste
     p.nvar = cfg.nvar;
     p.space_ooa = space_ooa;
     p.gamma = cfg.gamma;
+    // cells whose flag this part is the first to need: the faces of on-grid planes [kz0,kz1) touch
+    // planes kz0-1 .. kz1; a whole stage covers every cell incl. ghosts like the reference's loop
+    p.c0 = 0;
+    p.c1 = h->g.ncell;
+    if (!(first && last)) {
+      const int nb = h->g.nbc[2], nz = h->g.ng[2];
+      int lo = kz0 - 1, hi = kz1 + 1;        // on-grid plane numbers [lo,hi): the interior part
+      if (kz0 == 0) {                        // lower z-boundary part: the interior part did nb-1 ..
+        lo = -1;
+        hi = nb - 1;
+      }
+      else if (kz1 == nz) {                  // upper z-boundary part: the interior part did .. nz-nb
+        lo = nz - nb + 1;
+        hi = nz + 1;
+      }
+      p.c0 = (long)(lo + nb) * h->g.sz;
+      p.c1 = (long)(hi + nb) * h->g.sz;
+    }
     time_begin(h, 1);
     rc = cfg.strict_fp ? fp_strict::launch_prepass(p, h->stream) : fp_fast::launch_prepass(p, h->stream);
     time_end(h, 1);
@@ -731,12 +797,26 @@ int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_ste
   a.use_march = h->use_march;
   a.rows = h->rows;
   a.zchunk = h->zchunk;
+  a.kz0 = kz0;
+  a.kz1 = kz1;
   if (a.zchunk <= 0) {
     // planes per wavefront: long chunks amortise the priming plane, but keep >= ~4 wavefronts per SIMD
     // (1024 SIMDs) in flight so that the tail of the launch stays short
     const long per_plane_chunk = (long)((h->g.ng[0] + 61) / 62) * ((h->g.ng[1] + a.rows - 1) / a.rows);
     a.zchunk = 64;
-    while (a.zchunk > 8 && per_plane_chunk * ((h->g.ng[2] + a.zchunk - 1) / a.zchunk) < 4096) a.zchunk /= 2;
+    while (a.zchunk > 8 && per_plane_chunk * ((kz1 - kz0 + a.zchunk - 1) / a.zchunk) < 4096) a.zchunk /= 2;
+  }
+  // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
+  const bool fuse_dt = h->fuse_dt && is_full_step && a.use_march == 2 && h->g.ndim == 3 && h->g.nbc[2] >= 2
+                       && a.out == h->dP;
+  a.dtres = nullptr;
+  a.cfl = cfg.cfl;
+  a.dt_mp = (cfg.cooling != 0 && cfg.mp_timestep_limit != 0) ? 1 : 0;
+  h->dt_cached = false;
+  if (fuse_dt) {
+    if (first)
+      HCHECK(h, hipMemcpyAsync(h->ddt, h->ddt_init, 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    a.dtres = h->ddt;
   }
   time_begin(h, 0);
   rc = cfg.strict_fp ? fp_strict::launch_stage(a, h->stream) : fp_fast::launch_stage(a, h->stream);
@@ -745,13 +825,42 @@ int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_ste
     h->err = "stage kernel launch failed (unsupported eqn/solver/tracer combination?)";
     return PION_GPU_EDEVICE;
   }
+  if (!last) return 0;
   if (is_full_step && a.out == h->dPh) {
     // OA1/OA1: copy the result back to P ("P = Ph", time_integrator.cpp:938-939)
     const size_t nb = sizeof(double) * (size_t)cfg.nvar * h->g.ncell;
     HCHECK(h, hipMemcpyAsync(h->dP, h->dPh, nb, hipMemcpyDeviceToDevice, h->stream));
   }
   h->ph_valid = !is_full_step;
+  h->dt_cached = fuse_dt;
   return 0;
+}
+
+int pion_gpu_stage_part(void *handle, double dt_stage, int space_ooa, int is_full_step, int part)
+{
+  Handle *h = (Handle *)handle;
+  const int nz = h->g.ng[2], nb = h->g.nbc[2];
+  if (part == PION_STAGE_WHOLE) {
+    if (int rc = order_after_unpack(h)) return rc;
+    return stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nz, true, true);
+  }
+  const bool split = stage_can_split(h);
+  if (part == PION_STAGE_INTERIOR) {
+    if (!split) return 0;  // everything happens in the z-boundary call
+    return stage_launch(h, dt_stage, space_ooa, is_full_step, nb, nz - nb, true, false);
+  }
+  if (part != PION_STAGE_ZBOUNDARY) return PION_GPU_EINVAL;
+  // the z ghost planes must have arrived: order the compute stream after the last unpack
+  if (int rc = order_after_unpack(h)) return rc;
+  if (!split) return stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nz, true, true);
+  int rc = stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nb, false, false);
+  if (rc) return rc;
+  return stage_launch(h, dt_stage, space_ooa, is_full_step, nz - nb, nz, false, true);
+}
+
+int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_step)
+{
+  return pion_gpu_stage_part(handle, dt_stage, space_ooa, is_full_step, PION_STAGE_WHOLE);
 }
 
 int pion_gpu_advance_time(void *handle, double dt, double simtime)
@@ -782,9 +891,21 @@ static int halo_go(Handle *h, int which, int face, void *dbuf, int pack)
   if (h->cfg.ndim != 3 || (face != 4 && face != 5)) return PION_GPU_EINVAL;
   double *A = (which == 0) ? h->dP : h->dPh;
   const long n = pion_gpu_halo_count(h);
-  hipLaunchKernelGGL(k_halo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, A, (double *)dbuf, h->g,
+  hipStream_t cs = h->comm_stream ? h->comm_stream : h->stream;
+  if (cs != h->stream && pack) {
+    // the planes to send were written (stage) and their x/y ghosts filled (BCs) on the compute stream
+    if (!h->ev_packed_src) HCHECK(h, hipEventCreateWithFlags(&h->ev_packed_src, hipEventDisableTiming));
+    HCHECK(h, hipEventRecord(h->ev_packed_src, h->stream));
+    HCHECK(h, hipStreamWaitEvent(cs, h->ev_packed_src, 0));
+  }
+  hipLaunchKernelGGL(k_halo, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, cs, A, (double *)dbuf, h->g,
                      h->cfg.nvar, face, pack);
   HCHECK(h, hipGetLastError());
+  if (cs != h->stream && !pack) {
+    if (!h->ev_unpacked) HCHECK(h, hipEventCreateWithFlags(&h->ev_unpacked, hipEventDisableTiming));
+    HCHECK(h, hipEventRecord(h->ev_unpacked, cs));
+    h->ev_unpacked_valid = true;
+  }
   return 0;
 }
 int pion_gpu_pack_halo(void *handle, int which, int face, void *dbuf) { return halo_go((Handle *)handle, which, face, dbuf, 1); }
@@ -921,6 +1042,7 @@ int pion_gpu_get_timing(void *handle, double *out, int n)
       }
     }
     out[s] = cnt ? tot / cnt : 0.0;
+    if (4 + s < n) out[4 + s] = cnt;
   }
   return 0;
 }

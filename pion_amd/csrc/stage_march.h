@@ -82,7 +82,8 @@ PDEV void apply_axis(double *d, const double *q0, const double bnm, const double
 
 // CellAdvanceTime + temperature clamp + store (see k_stage)
 template <int EQ, int NTR>
-PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, const double *dU, int &err)
+PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, const double *dU, int &err,
+                           double *Pfout = nullptr)
 {
   typedef Eqn<EQ, NTR> E;
   constexpr int NV = E::NV;
@@ -108,6 +109,57 @@ PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, 
   }
 #pragma unroll
   for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v];
+  if (Pfout) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) Pfout[v] = Pf[v];
+  }
+}
+
+// CellTimeStep of a lab-frame state (solver_eqn_hydro_adi.cpp:460-502 / solver_eqn_mhd_adi.cpp:516-582);
+// the same operations as k_dt, used by the stage kernel to leave the next step's dt behind.
+template <int EQ>
+PDEV double cell_dt(const double *P, const int ndim, const double g, const double dx, const double cfl)
+{
+  double p[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) p[v] = (EQ != EQEUL || v < 5) ? P[v] : 0.0;
+  double temp;
+  if constexpr (EQ == EQEUL) {
+    temp = 0.0;
+    for (int v = 0; v < ndim; v++) temp += p[2 + v] * p[2 + v];
+    temp = sqrt(temp);
+    temp += Eqn<EQEUL, 0>::chydro(p, g);
+  }
+  else {
+    temp = fabs(p[2]);
+    if (ndim > 1) temp = dmax(temp, fabs(p[3]));
+    if (ndim > 2) temp = dmax(temp, fabs(p[4]));
+    if (ndim == 1) temp += Eqn<EQMHD, 0>::cfast(p, g);
+    else {
+      int newdir = 0;
+      if (fabs(p[6]) < fabs(p[5])) {
+        newdir = 1;
+        if (fabs(p[7]) < fabs(p[6])) newdir = 2;
+      }
+      else if (fabs(p[7]) < fabs(p[5])) newdir = 2;
+      double u1[8];
+      to_sweep<8, true>(newdir, p, u1);
+      temp += Eqn<EQMHD, 0>::cfast(u1, g);
+    }
+  }
+  double t = dx / temp;
+  t *= cfl;
+  return t;
+}
+
+PDEV double wave_min64(double v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double w = __shfl_xor(v, o, 64);
+    v = (w < v) ? w : v;
+  }
+  return v;
 }
 
 #define PION_MARCH_XT 62  // output cells per wavefront along x
@@ -124,7 +176,7 @@ __global__ __launch_bounds__(256) void k_stage_march(const StageArgs a)
   const int nzc = (a.g.ng[2] + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)ntx * a.g.ng[1] * nzc;
   // four independent wavefronts per workgroup, each with its own pencil
-  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + (threadIdx.x >> 6);
+  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (tile >= ntiles) return;  // whole wavefront leaves together
   const int tx = (int)(tile % ntx), iy = (int)((tile / ntx) % a.g.ng[1]), cz = (int)(tile / ((long)ntx * a.g.ng[1]));
   const int lane = threadIdx.x & 63;

@@ -29,9 +29,11 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
   const int R = a.rows;
   const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
   const int nyg = (a.g.ng[1] + R - 1) / R;
-  const int nzc = (a.g.ng[2] + a.zchunk - 1) / a.zchunk;
+  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)ntx * nyg * nzc;
-  const int wave = threadIdx.x >> 6;
+  // readfirstlane: tells the compiler the wavefront number (and the tile, row and plane loops that
+  // follow from it) is uniform, so they live in SGPRs and branch on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
   if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
   const int tx = (int)(tile % ntx), jg = (int)((tile / ntx) % nyg), cz = (int)(tile / ((long)ntx * nyg));
@@ -41,14 +43,15 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
   if (ix > a.g.ng[0]) ix = a.g.ng[0];
   const int j0 = jg * R;
   const int nrows = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
-  const int k0 = cz * a.zchunk;
-  const int k1 = (k0 + a.zchunk < a.g.ng[2]) ? k0 + a.zchunk : a.g.ng[2];
+  const int k0 = a.kz0 + cz * a.zchunk;
+  const int k1 = (k0 + a.zchunk < a.kz1) ? k0 + a.zchunk : a.kz1;
 
   const long nc = a.g.ncell, sy = a.g.sy, sz = a.g.sz;
   const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
   const bool oa2 = (a.space_ooa == 2);
   const bool hcorr = (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
   int err = 0;
+  double tdyn = 1.e100, tmp = 1.0e99;  // running minima for the fused time-step reduction
 
   // this wavefront's LDS: zst[row][slot][lane], slot 0..NV-1 = z slope, NV..2NV-1 = lower z flux
   const int zbase = wave * R * (2 * NV) * 64 + lane;
@@ -299,15 +302,37 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
       }
 
       if (!prime && writer) {
+        double Pf[NV];
         if (!(fl & 4) || !(fl & 16)) {
 #pragma unroll
-          for (int v = 0; v < NV; v++) a.out[v * nc + c] = P0[v];
+          for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v] = P0[v];
         }
-        else cell_update_store<EQ, NTR>(a, c, P0, dU, err);
+        else cell_update_store<EQ, NTR>(a, c, P0, dU, err, Pf);
+        if (a.dtres) {
+          // calc_dynamics_dt / calc_microphysics_dt (calc_timestep.cpp:271-507) of the state just
+          // written: after a full step it is the state the next step's dt is computed from
+          if ((fl & 8) && !(fl & 2)) {
+            const double t = cell_dt<EQ>(Pf, a.g.ndim, g, dx, a.cfl);
+            if (!(t > 0.0)) err |= ERR_BAD_DT;
+            tdyn = (t < tdyn) ? t : tdyn;
+          }
+          if (a.dt_mp && !(fl & 2) && (fl & 16)) {
+            const double t = Cooling::timescale(a.cool, Pf[qRO], Pf[qPG], g);
+            tmp = (t < tmp) ? t : tmp;
+          }
+        }
       }
     }
   }
 #undef ZS
+  if (a.dtres) {
+    tdyn = wave_min64(tdyn);
+    tmp = wave_min64(tmp);
+    if (lane == 0) {
+      atomicMin(&a.dtres[0], (unsigned long long)__double_as_longlong(tdyn));
+      atomicMin(&a.dtres[1], (unsigned long long)__double_as_longlong(tmp));
+    }
+  }
   if (err) atomicOr(a.errword, err);
 }
 
@@ -323,7 +348,7 @@ static int stage_rows_go(const StageArgs &a0, hipStream_t s)
   const int R = a.rows;
   const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
   const int nyg = (a.g.ng[1] + R - 1) / R;
-  const int nzc = (a.g.ng[2] + a.zchunk - 1) / a.zchunk;
+  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)ntx * nyg * nzc;
   const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
   const size_t shmem = sizeof(double) * 4 * R * (2 * NV) * 64;

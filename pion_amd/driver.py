@@ -33,10 +33,24 @@ class SimControl:
 
     def update_bcs(self, cstep, maxstep, assign=0):
         """TimeUpdateInternalBCs + TimeUpdateExternalBCs (+ slab halo exchange, which plays the
-        role of BC_update_BCMPI for the z faces, MCMD_boundaries.cpp:122-237)."""
+        role of BC_update_BCMPI for the z faces, MCMD_boundaries.cpp:122-237).  The exchange is only
+        started here; _stage() completes it between the interior and the z-boundary part."""
         self.sim.update_bcs(self.simtime, cstep, maxstep, assign)
         if self.comm is not None:
-            self.comm.exchange(self.sim, which=0 if cstep == maxstep else 1)
+            self.comm.start(self.sim, which=0 if cstep == maxstep else 1)
+
+    def _stage(self, dt, space_ooa, is_full):
+        if self.comm is None:
+            self.sim.stage(dt, space_ooa, is_full)
+            return
+        self.sim.stage_part(dt, space_ooa, is_full, abi.STAGE_INTERIOR)
+        self.comm.finish(self.sim)
+        self.sim.stage_part(dt, space_ooa, is_full, abi.STAGE_ZBOUNDARY)
+
+    def finish_halo(self):
+        """Complete a halo exchange still in flight (before the state is read back)."""
+        if self.comm is not None:
+            self.comm.finish(self.sim)
 
     # calc_timestep::calculate_timestep (calc_timestep.cpp:68-153)
     def calculate_timestep(self):
@@ -63,12 +77,12 @@ class SimControl:
     def advance_time(self):
         dt = self.dt
         if self.cfg.tm_ooa == abi.OA1 and self.cfg.sp_ooa == abi.OA1:
-            self.sim.stage(dt, abi.OA1, 1)
+            self._stage(dt, abi.OA1, 1)
             self.update_bcs(abi.OA1, abi.OA1)
         elif self.cfg.tm_ooa == abi.OA2 and self.cfg.sp_ooa == abi.OA2:
-            self.sim.stage(0.5 * dt, abi.OA1, 0)
+            self._stage(0.5 * dt, abi.OA1, 0)
             self.update_bcs(abi.OA1, abi.OA2)
-            self.sim.stage(dt, abi.OA2, 1)
+            self._stage(dt, abi.OA2, 1)
             self.update_bcs(abi.OA2, abi.OA2)
         else:
             raise RuntimeError("Bad OOA requests; choose (1,1) or (2,2)")
@@ -84,4 +98,5 @@ class SimControl:
             self.calculate_timestep()
             self.advance_time()
             n += 1
+        self.finish_halo()
         return n

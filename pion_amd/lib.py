@@ -31,6 +31,7 @@ def load_library():
         raise ImportError(
             "%s not found: build it with `make -C pion_amd/csrc` (or __graft_entry__.build()); "
             "pion_amd has no CPU fallback" % path)
+    abi.share_torch_hip_runtime()
     lib = C.CDLL(path)
     lib.pion_gpu_create.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.POINTER(C.c_void_p)]
     lib.pion_gpu_destroy.argtypes = [C.c_void_p]
@@ -44,6 +45,8 @@ def load_library():
     lib.pion_gpu_device_ptr.argtypes = [C.c_void_p, C.c_int]
     lib.pion_gpu_device_ptr.restype = C.c_void_p
     lib.pion_gpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pion_gpu_set_comm_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pion_gpu_stage_part.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int]
     lib.pion_gpu_synchronize.argtypes = [C.c_void_p]
     lib.pion_gpu_set_wind_cells.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_long), _dp]
     lib.pion_gpu_set_cooling_tables.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
@@ -74,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "pion_gpu_set_glm_speeds", "pion_gpu_stage", "pion_gpu_advance_time", "pion_gpu_halo_count",
     "pion_gpu_pack_halo", "pion_gpu_unpack_halo", "pion_gpu_interface_flux",
     "pion_gpu_cooling_update", "pion_gpu_cooling_edot", "pion_gpu_enable_timing",
-    "pion_gpu_get_timing",
+    "pion_gpu_get_timing", "pion_gpu_stage_part", "pion_gpu_set_comm_stream",
 ]
 
 
@@ -146,6 +149,9 @@ class GpuSim:
     def set_stream(self, stream_ptr):
         self._chk(self.lib.pion_gpu_set_stream(self.h, C.c_void_p(stream_ptr)), "set_stream")
 
+    def set_comm_stream(self, stream_ptr):
+        self._chk(self.lib.pion_gpu_set_comm_stream(self.h, C.c_void_p(stream_ptr)), "set_comm_stream")
+
     def synchronize(self):
         self._chk(self.lib.pion_gpu_synchronize(self.h), "synchronize")
 
@@ -176,6 +182,9 @@ class GpuSim:
 
     def stage(self, dt, space_ooa, is_full):
         self._chk(self.lib.pion_gpu_stage(self.h, dt, space_ooa, is_full), "stage")
+
+    def stage_part(self, dt, space_ooa, is_full, part):
+        self._chk(self.lib.pion_gpu_stage_part(self.h, dt, space_ooa, is_full, part), "stage_part")
 
     def advance_time(self, dt, simtime):
         self._chk(self.lib.pion_gpu_advance_time(self.h, dt, simtime), "advance_time")
@@ -221,6 +230,7 @@ class GpuSim:
         self._chk(self.lib.pion_gpu_enable_timing(self.h, int(on)), "enable_timing")
 
     def get_timing(self):
-        out = np.zeros(4)
-        self._chk(self.lib.pion_gpu_get_timing(self.h, _p(out), 4), "get_timing")
-        return {"stage_ms": out[0], "prepass_ms": out[1], "bc_ms": out[2], "dt_ms": out[3]}
+        out = np.zeros(8)
+        self._chk(self.lib.pion_gpu_get_timing(self.h, _p(out), 8), "get_timing")
+        return {"stage_ms": out[0], "prepass_ms": out[1], "bc_ms": out[2], "dt_ms": out[3],
+                "stage_n": int(out[4]), "prepass_n": int(out[5]), "bc_n": int(out[6]), "dt_n": int(out[7])}

@@ -47,6 +47,14 @@ def slab_slice(P_global, cfg_global, rank, world):
     return P_global[:, z0:z0 + nzl + 2 * nb].copy()
 
 
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class SlabComm:
     """Halo exchange + dt reduction for one rank.  `make_buffer(n)` returns a flat float64
     tensor on the device the backend computes on; backend.pack_halo/unpack_halo take
@@ -64,34 +72,68 @@ class SlabComm:
         mk = lambda: torch.empty(halo_count, dtype=torch.float64, device=device)
         self.send_up, self.send_down, self.recv_up, self.recv_down = mk(), mk(), mk(), mk()
         self.dtbuf = torch.empty(2, dtype=torch.float64, device=device)
+        self.pending = None
+        self.kstream = self.cstream = None
 
-    def exchange(self, sim, which):
+    def use_streams(self, sim):
+        """GPU ranks: kernels on one torch stream, halo pack / RCCL / unpack on a second (high
+        priority) one, ordered against each other inside the library (pion_gpu_set_comm_stream), so
+        that the exchange runs under the interior part of the next stage and the host never blocks."""
+        torch = self.torch
+        if not self.send_up.is_cuda:
+            return
+        sim.synchronize()
+        self.kstream = torch.cuda.Stream()
+        self.cstream = torch.cuda.Stream(priority=-1)
+        sim.set_stream(self.kstream.cuda_stream)
+        sim.set_comm_stream(self.cstream.cuda_stream)
+
+    def start(self, sim, which):
+        """Pack the on-grid planes next to the internal z faces of array `which` and post the
+        transfers.  Returns at once; finish() must follow before the ghost planes are read."""
         dist = self.dist
+        assert self.pending is None, "previous halo exchange not finished"
         if self.up is None and self.down is None:
             return
-        ops = []
-        if self.up is not None:
-            sim.pack_halo(which, 5, self.send_up.data_ptr())      # my top on-grid planes
-        if self.down is not None:
-            sim.pack_halo(which, 4, self.send_down.data_ptr())    # my bottom on-grid planes
-        sim.synchronize()
-        # order matters when up == down (2 ranks, periodic): first message = "top" planes
-        if self.up is not None:
-            ops.append(dist.P2POp(dist.isend, self.send_up, self.up))
-        if self.down is not None:
-            ops.append(dist.P2POp(dist.irecv, self.recv_down, self.down))
-        if self.down is not None:
-            ops.append(dist.P2POp(dist.isend, self.send_down, self.down))
-        if self.up is not None:
-            ops.append(dist.P2POp(dist.irecv, self.recv_up, self.up))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if self.recv_down.is_cuda:
-            self.torch.cuda.current_stream().synchronize()
-        if self.down is not None:
-            sim.unpack_halo(which, 4, self.recv_down.data_ptr())  # neighbour's top -> my ZN ghosts
-        if self.up is not None:
-            sim.unpack_halo(which, 5, self.recv_up.data_ptr())    # neighbour's bottom -> my ZP ghosts
+        ctx = self.torch.cuda.stream(self.cstream) if self.cstream is not None else _nullctx()
+        with ctx:
+            if self.up is not None:
+                sim.pack_halo(which, 5, self.send_up.data_ptr())      # my top on-grid planes
+            if self.down is not None:
+                sim.pack_halo(which, 4, self.send_down.data_ptr())    # my bottom on-grid planes
+            if self.cstream is None:
+                sim.synchronize()
+            # order matters when up == down (2 ranks, periodic): first message = "top" planes
+            ops = []
+            if self.up is not None:
+                ops.append(dist.P2POp(dist.isend, self.send_up, self.up))
+            if self.down is not None:
+                ops.append(dist.P2POp(dist.irecv, self.recv_down, self.down))
+            if self.down is not None:
+                ops.append(dist.P2POp(dist.isend, self.send_down, self.down))
+            if self.up is not None:
+                ops.append(dist.P2POp(dist.irecv, self.recv_up, self.up))
+            self.pending = (which, dist.batch_isend_irecv(ops))
+
+    def finish(self, sim):
+        if self.pending is None:
+            return
+        which, works = self.pending
+        self.pending = None
+        ctx = self.torch.cuda.stream(self.cstream) if self.cstream is not None else _nullctx()
+        with ctx:
+            for w in works:
+                w.wait()        # GPU: the comm stream waits for RCCL, the host does not
+            if self.cstream is None and self.recv_down.is_cuda:
+                self.torch.cuda.current_stream().synchronize()
+            if self.down is not None:
+                sim.unpack_halo(which, 4, self.recv_down.data_ptr())  # neighbour's top -> my ZN ghosts
+            if self.up is not None:
+                sim.unpack_halo(which, 5, self.recv_up.data_ptr())    # neighbour's bottom -> my ZP ghosts
+
+    def exchange(self, sim, which):
+        self.start(sim, which)
+        self.finish(sim)
 
     def allreduce_min(self, t_dyn, t_mp):
         if self.world == 1:

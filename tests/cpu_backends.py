@@ -171,6 +171,12 @@ class CpuSim:
     def stage(self, dt, space_ooa, is_full):
         self._chk(self._f("stage")(self.h, C.c_double(dt), C.c_int(space_ooa), C.c_int(is_full)), "stage")
 
+    def stage_part(self, dt, space_ooa, is_full, part):
+        # the oracle has no split: like the configurations pion_gpu_stage_part does not split,
+        # everything happens in the z-boundary call (abi.STAGE_ZBOUNDARY), after the halo arrived
+        if part != 1:
+            self.stage(dt, space_ooa, is_full)
+
     def setdt(self, dt):
         self._chk(self._f("setdt")(self.h, C.c_double(dt)), "setdt")
 

@@ -22,6 +22,7 @@ def test_library_exports_every_declared_symbol():
     from pion_amd import lib
     if not os.path.exists(abi.library_path()):
         pytest.skip("libpion_gpu.so not built (run __graft_entry__.build())")
+    abi.share_torch_hip_runtime()
     l = C.CDLL(abi.library_path())
     syms = _header_symbols()
     assert len(syms) >= 25

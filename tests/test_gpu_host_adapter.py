@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_cpp_time_int_equals_python_driver():
     from pion_amd import lib
+    abi.share_torch_hip_runtime()
     host = C.CDLL(os.path.join(ROOT, "pion_amd", "host", "libpion_host.so"))
     dp = C.POINTER(C.c_double)
     host.pion_host_sim_create.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.POINTER(C.c_void_p)]
