@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_stage_march(const StageArgs a)
   const int nzc = (a.g.ng[2] + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)ntx * a.g.ng[1] * nzc;
   // four independent wavefronts per workgroup, each with its own pencil
-  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + (threadIdx.x >> 6);
   if (tile >= ntiles) return;  // whole wavefront leaves together
   const int tx = (int)(tile % ntx), iy = (int)((tile / ntx) % a.g.ng[1]), cz = (int)(tile / ((long)ntx * a.g.ng[1]));
   const int lane = threadIdx.x & 63;

@@ -31,9 +31,15 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
   const int nyg = (a.g.ng[1] + R - 1) / R;
   const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)ntx * nyg * nzc;
-  // readfirstlane: tells the compiler the wavefront number (and the tile, row and plane loops that
-  // follow from it) is uniform, so they live in SGPRs and branch on the scalar unit
+  // PION_WAVE_UNIFORM (strict build, see Makefile): readfirstlane tells the compiler the wavefront
+  // number -- and the tile, row and plane loops that follow from it -- is uniform, so they live in SGPRs
+  // and branch on the scalar unit.  Measured 1 ms/launch slower at 512^3 (more SGPR spill traffic), so
+  // the fast build keeps the vector form.
+#ifdef PION_WAVE_UNIFORM
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+  const int wave = threadIdx.x >> 6;
+#endif
   const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
   if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
   const int tx = (int)(tile % ntx), jg = (int)((tile / ntx) % nyg), cz = (int)(tile / ((long)ntx * nyg));
