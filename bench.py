@@ -134,6 +134,16 @@ def main():
         # (N > 1 splits a stage into interior + 2 z-boundary launches: sum them per stage)
         stage_ms = tm["stage_ms"] * tm["stage_n"] / (2.0 * args.steps)
         achieved = alg_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+        # HBM-side bytes per stage launch from the PMC passes of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction calibrated on 8 B/lane
+        # accesses): profiles/r01_pmc_traffic.json, written by profiles/tools/summarize_r01.py.
+        # Counters cannot be read from inside this process, so the committed measurement is quoted
+        # when it is for this workload (512^3, GLM, fast mode, 1 GPU); otherwise null.
+        traffic = None
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if world == 1 and n == 512 and eq == abi.EQGLM and not args.strict and os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
         out = {
             "metric": "Mcell-updates/s on 3D ideal-MHD 512^3 uniform grid; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
@@ -144,7 +154,7 @@ def main():
                        "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world,
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "kernel": "k_stage_rows<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows<MHD,0,HLLD>",
                          "kernel_ms": stage_ms, "launches_per_stage": tm["stage_n"] / (2.0 * args.steps), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes},
