@@ -686,6 +686,360 @@ struct Solver : public Eqns {
   }
 
   // ---------------------------------------------------------------------
+  // FKJ98 linear MHD Riemann solver with Roe-Balsara eigenvectors
+  // (riemann_MHD::JMs_riemann_solve, Riemann_solvers/riemannMHD.cpp:165-405; speeds :555-766,
+  // eigenvalues :776-794, eigenvectors :965-1117, strengths :816-845, P* :849-963).
+  // Solver-frame ordering (riemannMHD.h:56-65): 0 rho, 1 p, 2 vx, 3 vy, 4 vz, 5 By, 6 Bz, 7 Bx.
+  // Wave ordering (riemannMHD.h:34-42): F-, A-, S-, contact, S+, A+, F+.
+  // The reference's rep.error() exits are thrown as physics_error.
+  int mhd_JMs_riemann_solve(const double *l, const double *r, double *ans, const int mode, const double g)
+  {
+    if (mode != FLUX_RSlinear) throw physics_error("riemann_MHD: MODE i: Don't know what to do.");
+    gamma = g;
+    const int map[8] = {eqRO, eqPG, eqVX, eqVY, eqVZ, eqBY, eqBZ, eqBX};  // code2solvervars :426-452
+    double L[8], R[8], M[8], star[8];
+    for (int i = 0; i < 8; i++) {
+      L[i] = l[map[i]];
+      R[i] = r[map[i]];
+    }
+    for (int i = 0; i < 8; i++) M[i] = 0.5 * (L[i] + R[i]);  // get_average_state :534-546
+    const double bxs = M[7];
+    star[7] = bxs;
+    double diff = 0.;
+    for (int i = 0; i < 7; i++) diff += std::fabs(R[i] - L[i]) / (std::fabs(refvec[i]) + TINYVALUE);
+    auto put_back = [&](const double *sv) {  // solver2codevars :480-509; entries > 7 stay 0
+      for (int v = 0; v < nvar; v++) ans[v] = 0.0;
+      for (int i = 0; i < 8; i++) ans[map[i]] = sv[i];
+    };
+    if (diff < 1.e-6) {
+      for (int i = 0; i < 7; i++) star[i] = M[i];
+      put_back(star);
+      return 0;
+    }
+    const double smallB = MACHINEACCURACY, tinyB = smallB * smallB * smallB;
+    // get_sound_speeds :555-766
+    const double ch = std::sqrt(g * M[1] / M[0]);
+    const double bx = bxs / std::sqrt(M[0]);
+    double ca = std::fabs(bx);
+    const double bt = std::sqrt((M[5] * M[5] + M[6] * M[6]) / M[0]);
+    double betay, betaz;
+    if (bt > tinyB) {
+      betay = M[5] / std::sqrt(M[0]) / bt;
+      betaz = M[6] / std::sqrt(M[0]) / bt;
+    }
+    else {
+      betay = 1. / std::sqrt(2.);
+      betaz = 1. / std::sqrt(2.);
+    }
+    if ((ch / std::max(ca, bt)) < std::sqrt(smallB))
+      throw physics_error("riemann_MHD::(get_sound_speeds) returned with error");
+    double t1 = ch * ch + bx * bx + bt * bt;
+    double t2 = 4. * ch * ch * bx * bx;
+    if ((t2 = t1 * t1 - t2) < MACHINEACCURACY) t2 = MACHINEACCURACY;
+    double cf = std::sqrt((t1 + std::sqrt(t2)) / 2.);
+    if ((t2 = t1 - std::sqrt(t2)) < MACHINEACCURACY) t2 = MACHINEACCURACY;
+    double cs = std::sqrt(t2 / 2.);
+    if (cs > ch) cs = ch - smallB;
+    if (ch > cf) cf = ch + smallB;
+    if (cs > ca) cs = ca - smallB;
+    if (cs <= 0. || cs > ca) cs = ca / 2.;
+    if (ca > cf) cf = ca + smallB;
+    double alphaf, alphas, cf2diff;
+    if ((cf2diff = cf * cf - cs * cs) > smallB) {
+      if ((alphaf = ch * ch - cs * cs) <= smallB) alphaf = 0.;
+      if ((alphas = cf * cf - ch * ch) <= smallB) alphas = 0.;
+      if ((alphaf = std::sqrt(alphaf / cf2diff)) > 1.) alphaf = 1.;
+      if ((alphas = std::sqrt(alphas / cf2diff)) > 1.) alphas = 1.;
+    }
+    else throw physics_error("riemann_MHD: near triple degeneracy point (Bugging out for now...)");
+    if ((cf <= 0.) || (cs < 0.) || (ca < 0.) || (ch <= 0.))
+      throw physics_error("riemann_MHD::(get_sound_speeds) returned with error");
+    // get_eigenvalues :776-794
+    const double ev[7] = {M[2] - cf, M[2] - ca, M[2] - cs, M[2], M[2] + cs, M[2] + ca, M[2] + cf};
+    // RoeBalsara_evectors :965-1117 (rows F-, A-, S-, C, S+, A+, F+; columns in solver ordering)
+    const double r2 = std::sqrt(2.);
+    const int sBx = (bxs < 0.) ? -1 : 1;
+    double le[7][7], re[7][7];
+    for (int w = 0; w < 7; w++)
+      for (int j = 0; j < 7; j++) le[w][j] = re[w][j] = 0.0;
+    const double sr0 = std::sqrt(M[0]);
+    le[0][2] = -alphaf * cf;
+    le[0][3] = alphas * cs * sBx * betay;
+    le[0][4] = alphas * cs * sBx * betaz;
+    le[0][1] = alphaf / M[0];
+    le[0][5] = alphas * ch * betay / sr0;
+    le[0][6] = alphas * ch * betaz / sr0;
+    le[1][3] = sBx * betaz / r2;
+    le[1][4] = -sBx * betay / r2;
+    le[1][5] = betaz / sr0 / r2;
+    le[1][6] = -betay / sr0 / r2;
+    le[2][2] = -alphas * cs;
+    le[2][3] = -alphaf * cf * sBx * betay;
+    le[2][4] = -alphaf * cf * sBx * betaz;
+    le[2][1] = alphas / M[0];
+    le[2][5] = -alphaf * ch * betay / sr0;
+    le[2][6] = -alphaf * ch * betaz / sr0;
+    le[3][0] = 1.;
+    le[3][1] = -1 / ch / ch;
+    // positive-going waves mirror the negative ones: velocities flip for S and F, fields flip for A
+    for (int pair = 0; pair < 3; pair++) {
+      const int n = pair, q = 6 - pair;
+      const double sv = (pair == 1) ? 1.0 : -1.0, sb = (pair == 1) ? -1.0 : 1.0;
+      le[q][2] = sv * le[n][2];
+      le[q][3] = sv * le[n][3];
+      le[q][4] = sv * le[n][4];
+      le[q][1] = le[n][1];
+      le[q][5] = sb * le[n][5];
+      le[q][6] = sb * le[n][6];
+    }
+    // the reference writes "-x" for the mirrored entries; sv*x with sv = -1.0 is the same bits,
+    // and for the Alfven pair the velocity entries are copied (sv = +1) and the fields negated
+    re[0][0] = alphaf * M[0];
+    re[0][2] = le[0][2];
+    re[0][3] = le[0][3];
+    re[0][4] = le[0][4];
+    re[0][1] = alphaf * M[0] * ch * ch;
+    re[0][5] = le[0][5] * M[0];
+    re[0][6] = le[0][6] * M[0];
+    re[1][3] = le[1][3];
+    re[1][4] = le[1][4];
+    re[1][5] = le[1][5] * M[0];
+    re[1][6] = le[1][6] * M[0];
+    re[2][0] = alphas * M[0];
+    re[2][2] = le[2][2];
+    re[2][3] = le[2][3];
+    re[2][4] = le[2][4];
+    re[2][1] = alphas * M[0] * ch * ch;
+    re[2][5] = le[2][5] * M[0];
+    re[2][6] = le[2][6] * M[0];
+    re[3][0] = 1.0;
+    for (int pair = 0; pair < 3; pair++) {
+      const int n = pair, q = 6 - pair;
+      const double sv = (pair == 1) ? 1.0 : -1.0, sb = (pair == 1) ? -1.0 : 1.0;
+      re[q][0] = re[n][0];
+      re[q][2] = sv * re[n][2];
+      re[q][3] = sv * re[n][3];
+      re[q][4] = sv * re[n][4];
+      re[q][1] = re[n][1];
+      re[q][5] = sb * re[n][5];
+      re[q][6] = sb * re[n][6];
+    }
+    const double a22 = 1. / (2. * ch * ch);
+    for (int j = 0; j < 7; j++) {
+      le[0][j] *= a22;
+      le[2][j] *= a22;
+      le[4][j] *= a22;
+      le[6][j] *= a22;
+    }
+    // calculate_wave_strengths :816-845 (dot product accumulates from 0.0 over the 7 entries in order)
+    double pd[7], str[7];
+    for (int j = 0; j < 7; j++) pd[j] = R[j] - L[j];
+    for (int w = 0; w < 7; w++) {
+      double t = 0.0;
+      for (int j = 0; j < 7; j++) t += le[w][j] * pd[j];
+      str[w] = t;
+    }
+    // get_pstar :849-963
+    {
+      int i = 0;
+      for (int j = 0; j < 7; j++) star[j] = L[j];
+      while ((i < 7) && (ev[i] < 0.)) {
+        for (int j = 0; j < 7; j++) star[j] += str[i] * re[i][j];
+        i++;
+      }
+      if (std::fabs(M[2]) < (1.e-4 * ch)) {
+        i = 6;
+        for (int j = 0; j < 7; j++) pd[j] = R[j];
+        while ((i >= 0) && (ev[i] > 0.)) {
+          for (int j = 0; j < 7; j++) pd[j] -= str[i] * re[i][j];
+          i--;
+        }
+        for (int v = 0; v < 7; v++) star[v] = 0.5 * (star[v] + pd[v]);
+      }
+    }
+    if (star[1] < 0.) star[1] = refvec[1] * BASEPG;
+    if (star[0] < 0.) star[0] = refvec[0] * BASEPG;
+    put_back(star);
+    return 0;
+  }
+
+  // ---------------------------------------------------------------------
+  // Roe flux solver for ideal MHD in conserved variables, symmetric form (Cargo & Gallice 1997;
+  // Riemann_Roe_MHD_CV::MHD_Roe_CV_flux_solver_symmetric, Roe_MHD_ConservedVar_solver.cpp:218-264):
+  // average :345-405, differences :417-462, speeds :473-551, eigenvalues + H-correction :563-607,
+  // strengths :615-686, right eigenvectors :699-821, flux :1074-1133, P* :299-331.
+  // Every step returns 0 in the reference, so the FKJ98 fallback of inviscid_flux never triggers.
+  int MHD_Roe_CV_flux_solver_symmetric(const double *left, const double *right, const double g,
+                                       const double hc_etamax, double *out_pstar, double *out_flux)
+  {
+    gamma = g;
+    double UL[MAXNV], UR[MAXNV];
+    mhd_PtoU(left, UL, g);
+    mhd_PtoU(right, UR, g);
+    const int eqHH = eqPG;  // the mean state holds the enthalpy in the pressure slot
+    auto enthalpy = [&](const double *p) {
+      return ((p[eqRO] * (p[eqVX] * p[eqVX] + p[eqVY] * p[eqVY] + p[eqVZ] * p[eqVZ]) / 2.0 +
+               (g * p[eqPG] / (g - 1.0)) + (p[eqBX] * p[eqBX] + p[eqBY] * p[eqBY] + p[eqBZ] * p[eqBZ])) /
+              p[eqRO]);
+    };
+    double mp[MAXNV];
+    for (int v = 0; v < nvar; v++) mp[v] = 0.0;  // Roe_meanp entries > 7 are never written
+    const double rl = std::sqrt(left[eqRO]), rr = std::sqrt(right[eqRO]);
+    const double lH = enthalpy(left), rH = enthalpy(right);
+    const double denom = 1.0 / (rl + rr);
+    mp[eqRO] = rl * rr;
+    mp[eqVX] = (rl * left[eqVX] + rr * right[eqVX]) * denom;
+    mp[eqVY] = (rl * left[eqVY] + rr * right[eqVY]) * denom;
+    mp[eqVZ] = (rl * left[eqVZ] + rr * right[eqVZ]) * denom;
+    mp[eqBY] = (rr * left[eqBY] + rl * right[eqBY]) * denom;
+    mp[eqBZ] = (rr * left[eqBZ] + rl * right[eqBZ]) * denom;
+    mp[eqBX] = 0.5 * (left[eqBX] + right[eqBX]);
+    const int sgn = (mp[eqBX] >= 0.0) ? 1 : -1;
+    mp[eqHH] = (rl * lH + rr * rH) * denom;
+    const double V = std::sqrt(mp[eqVX] * mp[eqVX] + mp[eqVY] * mp[eqVY] + mp[eqVZ] * mp[eqVZ]);
+    const double B = std::sqrt(mp[eqBX] * mp[eqBX] + mp[eqBY] * mp[eqBY] + mp[eqBZ] * mp[eqBZ]);
+    const double Bt = std::sqrt(mp[eqBY] * mp[eqBY] + mp[eqBZ] * mp[eqBZ]);
+    double by, bz;
+    if (Bt >= TINYVALUE) {
+      by = mp[eqBY] / Bt;
+      bz = mp[eqBZ] / Bt;
+    }
+    else {
+      by = 1.0 / std::sqrt(2.0);
+      bz = 1.0 / std::sqrt(2.0);
+    }
+    // differences :417-462
+    double ud[MAXNV], pd[MAXNV];
+    for (int v = 0; v < nvar; v++) {
+      ud[v] = UR[v] - UL[v];
+      pd[v] = right[v] - left[v];
+    }
+    ud[eqBBX] = pd[eqBX] = 0.0;
+    const double X = (pd[eqBY] * pd[eqBY] + pd[eqBZ] * pd[eqBZ]) * 0.5 * denom * denom;
+    pd[eqPG] = ((0.5 * V * V - X) * pd[eqRO] -
+                (mp[eqVX] * ud[eqMMX] + mp[eqVY] * ud[eqMMY] + mp[eqVZ] * ud[eqMMZ]) + ud[eqERG] -
+                (mp[eqBY] * pd[eqBY] + mp[eqBZ] * pd[eqBZ])) *
+               (g - 1.0);
+    // wave speeds :473-551
+    const double b2 = B * B / mp[eqRO];
+    const double a = std::sqrt((2.0 - g) * X + (g - 1.0) * std::max((mp[eqHH] - 0.5 * V * V - b2), 1.0e-12 * V * V));
+    const double astar2 = a * a + b2;
+    double ca = std::sqrt(mp[eqBX] * mp[eqBX] / mp[eqRO]);
+    double cs = astar2 * astar2 - 4.0 * a * a * ca * ca;
+    if (cs <= 0.0) cs = 0.0;
+    else cs = std::sqrt(cs);
+    const double cf = std::sqrt(0.5 * (astar2 + cs));
+    cs = astar2 - cs;
+    if (cs <= 0.0) cs = 0.0;
+    else cs = std::sqrt(0.5 * cs);
+    if (ca > cf) ca = cf;
+    if (cs > ca) cs = ca;
+    double af, as, cf2diff;
+    if ((cf2diff = cf * cf - cs * cs) > MACHINEACCURACY) {
+      if ((af = a * a - cs * cs) < 0.0) af = 0.;
+      if ((as = cf * cf - a * a) < 0.0) as = 0.;
+      if ((af = std::sqrt(af / cf2diff)) > 1.0) af = 1.0;
+      if ((as = std::sqrt(as / cf2diff)) > 1.0) as = 1.0;
+    }
+    else af = as = 1.0 / std::sqrt(2.0);
+    // eigenvalues + H-correction :563-607
+    double ev[7] = {mp[eqVX] - cf, mp[eqVX] - ca, mp[eqVX] - cs, mp[eqVX], mp[eqVX] + cs, mp[eqVX] + ca,
+                    mp[eqVX] + cf};
+    for (int v = 0; v < 7; v++) {
+      if (ev[v] < 0.0) ev[v] = std::min(ev[v], -hc_etamax);
+      else ev[v] = std::max(ev[v], hc_etamax);
+    }
+    // wave strengths (CG97 4.20) :615-686
+    double st[7];
+    const double ro = mp[eqRO], sro = std::sqrt(mp[eqRO]);
+    st[0] = 0.5 * (af * (X * pd[eqRO] + pd[eqPG]) + ro * as * cs * sgn * (by * pd[eqVY] + bz * pd[eqVZ]) -
+                   ro * af * cf * pd[eqVX] + sro * as * a * (by * pd[eqBY] + bz * pd[eqBZ]));
+    st[6] = 0.5 * (af * (X * pd[eqRO] + pd[eqPG]) - ro * as * cs * sgn * (by * pd[eqVY] + bz * pd[eqVZ]) +
+                   ro * af * cf * pd[eqVX] + sro * as * a * (by * pd[eqBY] + bz * pd[eqBZ]));
+    st[2] = 0.5 * (as * (X * pd[eqRO] + pd[eqPG]) - ro * af * cf * sgn * (by * pd[eqVY] + bz * pd[eqVZ]) -
+                   ro * as * cs * pd[eqVX] - sro * af * a * (by * pd[eqBY] + bz * pd[eqBZ]));
+    st[4] = 0.5 * (as * (X * pd[eqRO] + pd[eqPG]) + ro * af * cf * sgn * (by * pd[eqVY] + bz * pd[eqVZ]) +
+                   ro * as * cs * pd[eqVX] - sro * af * a * (by * pd[eqBY] + bz * pd[eqBZ]));
+    st[1] = 0.5 * (+by * pd[eqVZ] - bz * pd[eqVY] + sgn * (by * pd[eqBZ] - bz * pd[eqBY]) / sro);
+    st[5] = 0.5 * (-by * pd[eqVZ] + bz * pd[eqVY] + sgn * (by * pd[eqBZ] - bz * pd[eqBY]) / sro);
+    st[3] = (a * a - X) * pd[eqRO] - pd[eqPG];
+    // right eigenvectors :699-821; columns: rho, mx, my, mz, By, Bz, E
+    double re[7][7];
+    re[3][0] = 1;
+    re[3][1] = mp[eqVX];
+    re[3][2] = mp[eqVY];
+    re[3][3] = mp[eqVZ];
+    re[3][4] = 0.0;
+    re[3][5] = 0.0;
+    re[3][6] = 0.5 * V * V + X * (g - 2) / (g - 1);
+    for (int v = 0; v < 7; v++) re[3][v] /= a * a;
+    re[1][0] = 0.0;
+    re[1][1] = 0.0;
+    re[1][2] = -ro * bz;
+    re[1][3] = +ro * by;
+    re[1][4] = -sgn * sro * bz;
+    re[1][5] = +sgn * sro * by;
+    re[1][6] = -ro * (mp[eqVY] * bz - mp[eqVZ] * by);
+    re[5][0] = 0.0;
+    re[5][1] = 0.0;
+    re[5][2] = -re[1][2];
+    re[5][3] = -re[1][3];
+    re[5][4] = re[1][4];
+    re[5][5] = re[1][5];
+    re[5][6] = -re[1][6];
+    const double das = ro * as, daf = ro * af;
+    re[2][0] = das;
+    re[2][1] = das * (mp[eqVX] - cs);
+    re[2][2] = das * mp[eqVY] - daf * cf * by * sgn;
+    re[2][3] = das * mp[eqVZ] - daf * cf * bz * sgn;
+    re[2][4] = -sro * af * a * by;
+    re[2][5] = -sro * af * a * bz;
+    re[2][6] = das * (mp[eqHH] - B * B / ro - mp[eqVX] * cs) - daf * cf * sgn * (mp[eqVY] * by + mp[eqVZ] * bz) -
+               sro * af * a * Bt;
+    re[4][0] = das;
+    re[4][1] = das * (mp[eqVX] + cs);
+    re[4][2] = das * mp[eqVY] + daf * cf * by * sgn;
+    re[4][3] = das * mp[eqVZ] + daf * cf * bz * sgn;
+    re[4][4] = re[2][4];
+    re[4][5] = re[2][5];
+    re[4][6] = das * (mp[eqHH] - B * B / ro + mp[eqVX] * cs) + daf * cf * sgn * (mp[eqVY] * by + mp[eqVZ] * bz) -
+               sro * af * a * Bt;
+    re[0][0] = daf;
+    re[0][1] = daf * (mp[eqVX] - cf);
+    re[0][2] = daf * mp[eqVY] + das * cs * by * sgn;
+    re[0][3] = daf * mp[eqVZ] + das * cs * bz * sgn;
+    re[0][4] = sro * as * a * by;
+    re[0][5] = sro * as * a * bz;
+    re[0][6] = daf * (mp[eqHH] - B * B / ro - mp[eqVX] * cf) + das * cs * sgn * (mp[eqVY] * by + mp[eqVZ] * bz) +
+               sro * as * a * Bt;
+    re[6][0] = daf;
+    re[6][1] = daf * (mp[eqVX] + cf);
+    re[6][2] = daf * mp[eqVY] - das * cs * by * sgn;
+    re[6][3] = daf * mp[eqVZ] - das * cs * bz * sgn;
+    re[6][4] = re[0][4];
+    re[6][5] = re[0][5];
+    re[6][6] = daf * (mp[eqHH] - B * B / ro + mp[eqVX] * cf) - das * cs * sgn * (mp[eqVY] * by + mp[eqVZ] * bz) +
+               sro * as * a * Bt;
+    const double norm = ro * a * a;
+    for (int v = 0; v < 7; v++) re[2][v] /= norm;
+    for (int v = 0; v < 7; v++) re[4][v] /= norm;
+    for (int v = 0; v < 7; v++) re[0][v] /= norm;
+    for (int v = 0; v < 7; v++) re[6][v] /= norm;
+    // symmetric flux :1074-1133
+    mhd_PUtoFlux(left, UL, out_flux);
+    mhd_PUtoFlux(right, UR, UL);
+    for (int v = 0; v < 8; v++) out_flux[v] += UL[v];
+    const int col[7] = {eqRHO, eqMMX, eqMMY, eqMMZ, eqBBY, eqBBZ, eqERG};
+    for (int w = 0; w < 7; w++)
+      for (int c = 0; c < 7; c++) out_flux[col[c]] -= st[w] * std::fabs(ev[w]) * re[w][c];
+    for (int v = 0; v < 8; v++) out_flux[v] *= 0.5;
+    // set_pstar_from_meanp :299-331
+    for (int v = 0; v < nvar; v++) out_pstar[v] = mp[v];
+    out_pstar[eqPG] = out_pstar[eqRO] * a * a / g;
+    return 0;
+  }
+
+  // ---------------------------------------------------------------------
   // HLLD / HLL (MHD): HLLD_MHD.cpp:124-333, 342-368, 377-417
   void HLLD_signal_speeds(const double *Pl, const double *Pr, const double g, double &Sl, double &Sr) const
   {
@@ -908,7 +1262,19 @@ struct Solver : public Eqns {
       err += MHD_HLL_flux_solver(Pl, Pr, g, flux, ustar);
       err = UtoP(ustar, pstar, MinTemperature, g);
     }
-    else throw physics_error("oracle: MHD flux solver not restated (Roe-MHD / linear MHD)");
+    else if (solve_flag == FLUX_RSroe) {
+      err += MHD_Roe_CV_flux_solver_symmetric(Pl, Pr, g, HC_etamax, pstar, flux);
+      if (err) {  // (never: every step of the Roe solver returns 0)
+        err = mhd_JMs_riemann_solve(Pl, Pr, pstar, 1, g);
+        PtoFlux(pstar, flux, g);
+      }
+    }
+    else if (solve_flag == FLUX_RSlinear || solve_flag == FLUX_RSexact || solve_flag == FLUX_RShybrid) {
+      // modes 2 and 3 are fatal inside the solver (riemannMHD.cpp:176-181)
+      err += mhd_JMs_riemann_solve(Pl, Pr, pstar, solve_flag, g);
+      PtoFlux(pstar, flux, g);
+    }
+    else throw physics_error("what sort of flux solver do you mean???");
     return err;
   }
   int glm_inviscid_flux(const double dx, const double *Pl, const double *Pr, double *flux,

@@ -33,11 +33,9 @@ from cpu_backends import CpuSim  # noqa: E402
 import golden_cases as gc  # noqa: E402
 
 
-def main():
-    rng = np.random.default_rng(20240611)
-    # ---- interface-flux KATs
+def flux_kats(rng, cases, fname):
     out = {}
-    for (eq, sv, ntr, av) in gc.flux_cases():
+    for (eq, sv, ntr, av) in cases:
         cfg = gc.flux_cfg(eq, sv, ntr, av)
         L, R = problems.random_states(rng, gc.NFLUX, eq, ntr)
         aux = np.zeros((gc.NFLUX, 4))
@@ -52,7 +50,39 @@ def main():
             for ax in range(3):
                 F, _ = r.interface_flux(ax, L, R, aux, dt=gc.GLM_DT)
                 out[key + "_F%d" % ax] = F
-    np.savez_compressed(os.path.join(HERE, "flux_kat.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+def step_dumps(cases, fname):
+    out = {}
+    for name in cases:
+        cfg, P = gc.step_case(name)
+        with CpuSim(cfg, "ref") as r:
+            sc = driver.SimControl(r, cfg)
+            sc.init(P)
+            out[name + "_bc"] = r.download(0).astype(np.float64)
+            dts = []
+            for _ in range(gc.NSTEPS):
+                dts.append(sc.calculate_timestep())
+                sc.advance_time()
+            out[name + "_dt"] = np.array(dts)
+            out[name + "_P"] = r.download(0)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+
+
+def main_b():
+    """flux_kat_b.npz: Roe-MHD and linear-MHD interface fluxes (added after the first set; separate
+    seed and file so that the vectors of flux_kat.npz stay what they were)"""
+    flux_kats(np.random.default_rng(20240612), gc.flux_cases_b(), "flux_kat_b.npz")
+    step_dumps(gc.STEP_CASES_B, "steps_b.npz")
+    for f in ("flux_kat_b.npz", "steps_b.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+def main():
+    rng = np.random.default_rng(20240611)
+    # ---- interface-flux KATs
+    flux_kats(rng, gc.flux_cases(), "flux_kat.npz")
 
     # ---- cell KATs
     out = {}
@@ -68,20 +98,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "cell_kat.npz"), **out)
 
     # ---- whole-grid steps
-    out = {}
-    for name in gc.STEP_CASES:
-        cfg, P = gc.step_case(name)
-        with CpuSim(cfg, "ref") as r:
-            sc = driver.SimControl(r, cfg)
-            sc.init(P)
-            out[name + "_bc"] = r.download(0).astype(np.float64)
-            dts = []
-            for _ in range(gc.NSTEPS):
-                dts.append(sc.calculate_timestep())
-                sc.advance_time()
-            out[name + "_dt"] = np.array(dts)
-            out[name + "_P"] = r.download(0)
-    np.savez_compressed(os.path.join(HERE, "steps.npz"), **out)
+    step_dumps(gc.STEP_CASES, "steps.npz")
     # ---- Cash-Karp integrator KAT: the REFERENCE's Integrator_Base (microphysics/integrator.cpp)
     # integrating dE/dt = f(E), f piecewise linear (see gc.ode_table)
     import ctypes as C
@@ -101,4 +118,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "b":
+        main_b()
+    else:
+        main()
+        main_b()

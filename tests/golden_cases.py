@@ -23,6 +23,19 @@ def flux_cases():
     return cases
 
 
+def flux_cases_b():
+    """second fixture file (flux_kat_b.npz, own seed so that the first file's vectors never move):
+    Roe-MHD (solver 4, with and without the H-correction eta) and the FKJ98 linear MHD solver (1)"""
+    cases = []
+    for eq in (abi.EQMHD, abi.EQGLM):
+        for ntr in (0, 1):
+            for av in (0, 1, 4):
+                cases.append((eq, abi.FLUX_RSroe, ntr, av))
+            for av in (0, 1):
+                cases.append((eq, abi.FLUX_RSlinear, ntr, av))
+    return cases
+
+
 def flux_cfg(eq, sv, ntr, av, strict_fp=1):
     return abi.make_config(3, [4, 4, 4], eq, sv, ntracer=ntr, artvisc=av, xmax=(1, 1, 1), strict_fp=strict_fp)
 
@@ -66,7 +79,19 @@ STEP_CASES = ["hd_roe_3d", "hd_fvs_2d_tr", "hd_roe_hcorr_2d", "hd_hll_1d", "mhd_
               "glm_mixed_2d", "dmr_2d", "hd_lf_oa1_3d"]
 
 
+STEP_CASES_B = ["mhd_roe_hcorr_2d", "glm_roe_3d", "glm_linear_2d"]   # steps_b.npz (added with flux_kat_b.npz)
+
+
 def step_case(name, strict_fp=1):
+    if name == "mhd_roe_hcorr_2d":
+        cfg, P = problems.mhd_blastwave(24, 2, abi.EQMHD, abi.FLUX_RSroe, strict_fp=strict_fp)
+        cfg.artvisc = abi.AV_HCORR_FKJ98
+        return cfg, P
+    if name == "glm_roe_3d":
+        return problems.mhd_blastwave(12, 3, abi.EQGLM, abi.FLUX_RSroe, strict_fp=strict_fp)
+    if name == "glm_linear_2d":
+        return problems.mhd_smooth(20, 2, abi.EQGLM, abi.FLUX_RSlinear, strict_fp=strict_fp,
+                                   bcs=["outflow", "one-way-outflow", "reflecting", "outflow"])
     if name == "hd_roe_3d":
         return problems.hd_blast_octant(12, 3, solver=abi.FLUX_RSroe, strict_fp=strict_fp, nzones=3.0)
     if name == "hd_fvs_2d_tr":

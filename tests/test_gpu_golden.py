@@ -20,15 +20,24 @@ def _gpu(cfg):
 
 @pytest.fixture(scope="module")
 def flux_kat():
-    return np.load(os.path.join(GOLD, "flux_kat.npz"))
+    """flux_kat.npz and flux_kat_b.npz (Roe-MHD / linear MHD, added later) as one key -> array map"""
+    d = {}
+    for f in ("flux_kat.npz", "flux_kat_b.npz"):
+        z = np.load(os.path.join(GOLD, f))
+        d.update({k: z[k] for k in z.files})
+    return d
 
 
 @pytest.fixture(scope="module")
 def steps():
-    return np.load(os.path.join(GOLD, "steps.npz"))
+    d = {}
+    for f in ("steps.npz", "steps_b.npz"):
+        z = np.load(os.path.join(GOLD, f))
+        d.update({k: z[k] for k in z.files})
+    return d
 
 
-@pytest.mark.parametrize("case", gc.flux_cases(), ids=lambda c: gc.flux_key(*c))
+@pytest.mark.parametrize("case", gc.flux_cases() + gc.flux_cases_b(), ids=lambda c: gc.flux_key(*c))
 def test_flux_kat_gpu(flux_kat, case):
     eq, sv, ntr, av = case
     key = gc.flux_key(*case)
@@ -48,7 +57,7 @@ def test_flux_kat_gpu(flux_kat, case):
                 assert np.array_equal(F, want, equal_nan=True), (key, ax)
 
 
-@pytest.mark.parametrize("name", gc.STEP_CASES)
+@pytest.mark.parametrize("name", gc.STEP_CASES + gc.STEP_CASES_B)
 def test_whole_steps_gpu(steps, name):
     cfg, P = gc.step_case(name)
     with _gpu(cfg) as g:

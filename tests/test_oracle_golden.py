@@ -14,7 +14,12 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 @pytest.fixture(scope="module")
 def flux_kat():
-    return np.load(os.path.join(GOLD, "flux_kat.npz"))
+    """flux_kat.npz and flux_kat_b.npz (Roe-MHD / linear MHD, added later) as one key -> array map"""
+    d = {}
+    for f in ("flux_kat.npz", "flux_kat_b.npz"):
+        z = np.load(os.path.join(GOLD, f))
+        d.update({k: z[k] for k in z.files})
+    return d
 
 
 @pytest.fixture(scope="module")
@@ -24,10 +29,14 @@ def cell_kat():
 
 @pytest.fixture(scope="module")
 def steps():
-    return np.load(os.path.join(GOLD, "steps.npz"))
+    d = {}
+    for f in ("steps.npz", "steps_b.npz"):
+        z = np.load(os.path.join(GOLD, f))
+        d.update({k: z[k] for k in z.files})
+    return d
 
 
-@pytest.mark.parametrize("case", gc.flux_cases(), ids=lambda c: gc.flux_key(*c))
+@pytest.mark.parametrize("case", gc.flux_cases() + gc.flux_cases_b(), ids=lambda c: gc.flux_key(*c))
 def test_flux_kat(flux_kat, case):
     eq, sv, ntr, av = case
     key = gc.flux_key(*case)
@@ -51,7 +60,7 @@ def test_cell_kat(cell_kat, case):
         assert np.array_equal(o.cell_timestep(P), cell_kat[key + "_dt"], equal_nan=True)
 
 
-@pytest.mark.parametrize("name", gc.STEP_CASES)
+@pytest.mark.parametrize("name", gc.STEP_CASES + gc.STEP_CASES_B)
 def test_whole_steps(steps, name):
     cfg, P = gc.step_case(name)
     with CpuSim(cfg, "orc") as o:
@@ -66,6 +75,6 @@ def test_whole_steps(steps, name):
 
 
 def test_fixtures_cover_all_flux_solvers(flux_kat):
-    keys = {k.rsplit("_", 1)[0] for k in flux_kat.files}
-    for c in gc.flux_cases():
+    keys = {k.rsplit("_", 1)[0] for k in flux_kat}
+    for c in gc.flux_cases() + gc.flux_cases_b():
         assert gc.flux_key(*c) in keys
