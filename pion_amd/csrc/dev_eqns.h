@@ -37,7 +37,7 @@ enum { qRO = 0, qPG = 1, qVN = 2, qVT1 = 3, qVT2 = 4, qBN = 5, qBT1 = 6, qBT2 = 
 enum { uRHO = 0, uERG = 1, uMN = 2, uMT1 = 3, uMT2 = 4, uBN = 5, uBT1 = 6, uBT2 = 7, uPSI = 8 };
 
 // error bits reported through the device error word
-enum { ERR_NEG_DENSITY = 1, ERR_RIEMANN_INPUT = 2, ERR_COOLING = 4, ERR_BAD_DT = 8 };
+enum { ERR_NEG_DENSITY = 1, ERR_RIEMANN_INPUT = 2, ERR_COOLING = 4, ERR_BAD_DT = 8, ERR_MHD_RIEMANN = 16 };
 
 // std::max / std::min semantics (not fmax/fmin: NaN behaviour differs)
 PDEV double dmax(double a, double b) { return (a < b) ? b : a; }

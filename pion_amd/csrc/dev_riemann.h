@@ -34,6 +34,7 @@ struct FluxCtx {
   double chyp;        // GLM_chyp
   double min_temp;    // EP.MinTemperature
   double refRO, refPG, refV;  // eq_refvec[RO], [PG], [VX..VZ] (all three velocities equal)
+  double refB;                // eq_refvec[BX..BZ] (MHD: all three equal, eqns_mhd_adiabatic.cpp:529-537)
   int gndim;          // FV_gndim
   int artvisc;
   MPd mp;
@@ -819,6 +820,373 @@ struct Flux {
     }
   }
 
+  // ------------------------------------------------------------------ FKJ98 linear MHD solver
+  // riemann_MHD::JMs_riemann_solve (riemannMHD.cpp:165-405) with the Roe-Balsara eigenvectors
+  // (:965-1117); sweep frame, so the solver ordering rho,p,vx,vy,vz,By,Bz(,Bx) is slots
+  // 0,1,2,3,4,6,7(,5).  Waves: F-, A-, S-, contact, S+, A+, F+.  The data-dependent wave loops of
+  // get_pstar (:849-963) are unrolled with a running predicate (no dynamic register indexing).
+  // The reference's fatal exits (rep.error) raise ERR_MHD_RIEMANN.
+  static PDEV void jm_mhd_linear(const double *l, const double *r, double *ans, const FluxCtx &c, int &err)
+  {
+    const double g = c.gamma;
+    constexpr int map[8] = {qRO, qPG, qVN, qVT1, qVT2, qBT1, qBT2, qBN};
+    double L[8], R[8], M[8], star[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      L[i] = l[map[i]];
+      R[i] = r[map[i]];
+      M[i] = 0.5 * (L[i] + R[i]);
+    }
+    const double bxs = M[7];
+    star[7] = bxs;
+    const double refv[7] = {c.refRO, c.refPG, c.refV, c.refV, c.refV, c.refB, c.refB};
+    double diff = 0.;
+#pragma unroll
+    for (int i = 0; i < 7; i++) diff += fabs(R[i] - L[i]) / (fabs(refv[i]) + PION_TINYVALUE);
+#pragma unroll
+    for (int v = 0; v < NV; v++) ans[v] = 0.0;
+    if (diff < 1.e-6) {
+#pragma unroll
+      for (int i = 0; i < 7; i++) star[i] = M[i];
+#pragma unroll
+      for (int i = 0; i < 8; i++) ans[map[i]] = star[i];
+      return;
+    }
+    const double smallB = PION_MACHINEACCURACY, tinyB = smallB * smallB * smallB;
+    const double ch = sqrt(g * M[1] / M[0]);
+    const double bx = bxs / sqrt(M[0]);
+    const double ca = fabs(bx);
+    const double bt = sqrt((M[5] * M[5] + M[6] * M[6]) / M[0]);
+    double betay, betaz;
+    if (bt > tinyB) {
+      betay = M[5] / sqrt(M[0]) / bt;
+      betaz = M[6] / sqrt(M[0]) / bt;
+    }
+    else {
+      betay = 1. / sqrt(2.);
+      betaz = 1. / sqrt(2.);
+    }
+    if ((ch / dmax(ca, bt)) < sqrt(smallB)) err |= ERR_MHD_RIEMANN;
+    double t1 = ch * ch + bx * bx + bt * bt;
+    double t2 = 4. * ch * ch * bx * bx;
+    if ((t2 = t1 * t1 - t2) < PION_MACHINEACCURACY) t2 = PION_MACHINEACCURACY;
+    double cf = sqrt((t1 + sqrt(t2)) / 2.);
+    if ((t2 = t1 - sqrt(t2)) < PION_MACHINEACCURACY) t2 = PION_MACHINEACCURACY;
+    double cs = sqrt(t2 / 2.);
+    if (cs > ch) cs = ch - smallB;
+    if (ch > cf) cf = ch + smallB;
+    if (cs > ca) cs = ca - smallB;
+    if (cs <= 0. || cs > ca) cs = ca / 2.;
+    if (ca > cf) cf = ca + smallB;
+    double alphaf, alphas, cf2diff;
+    if ((cf2diff = cf * cf - cs * cs) > smallB) {
+      if ((alphaf = ch * ch - cs * cs) <= smallB) alphaf = 0.;
+      if ((alphas = cf * cf - ch * ch) <= smallB) alphas = 0.;
+      if ((alphaf = sqrt(alphaf / cf2diff)) > 1.) alphaf = 1.;
+      if ((alphas = sqrt(alphas / cf2diff)) > 1.) alphas = 1.;
+    }
+    else {
+      err |= ERR_MHD_RIEMANN;  // "near triple degeneracy point ... Bugging out"
+      alphaf = alphas = 1. / sqrt(2.);
+    }
+    if ((cf <= 0.) || (cs < 0.) || (ca < 0.) || (ch <= 0.)) err |= ERR_MHD_RIEMANN;
+    const double ev[7] = {M[2] - cf, M[2] - ca, M[2] - cs, M[2], M[2] + cs, M[2] + ca, M[2] + cf};
+    const double r2 = sqrt(2.);
+    const int sBx = (bxs < 0.) ? -1 : 1;
+    double le[7][7], re[7][7];
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) le[w][j] = re[w][j] = 0.0;
+    }
+    const double sr0 = sqrt(M[0]);
+    le[0][2] = -alphaf * cf;
+    le[0][3] = alphas * cs * sBx * betay;
+    le[0][4] = alphas * cs * sBx * betaz;
+    le[0][1] = alphaf / M[0];
+    le[0][5] = alphas * ch * betay / sr0;
+    le[0][6] = alphas * ch * betaz / sr0;
+    le[1][3] = sBx * betaz / r2;
+    le[1][4] = -sBx * betay / r2;
+    le[1][5] = betaz / sr0 / r2;
+    le[1][6] = -betay / sr0 / r2;
+    le[2][2] = -alphas * cs;
+    le[2][3] = -alphaf * cf * sBx * betay;
+    le[2][4] = -alphaf * cf * sBx * betaz;
+    le[2][1] = alphas / M[0];
+    le[2][5] = -alphaf * ch * betay / sr0;
+    le[2][6] = -alphaf * ch * betaz / sr0;
+    le[3][0] = 1.;
+    le[3][1] = -1 / ch / ch;
+    re[0][0] = alphaf * M[0];
+    re[0][2] = le[0][2];
+    re[0][3] = le[0][3];
+    re[0][4] = le[0][4];
+    re[0][1] = alphaf * M[0] * ch * ch;
+    re[0][5] = le[0][5] * M[0];
+    re[0][6] = le[0][6] * M[0];
+    re[1][3] = le[1][3];
+    re[1][4] = le[1][4];
+    re[1][5] = le[1][5] * M[0];
+    re[1][6] = le[1][6] * M[0];
+    re[2][0] = alphas * M[0];
+    re[2][2] = le[2][2];
+    re[2][3] = le[2][3];
+    re[2][4] = le[2][4];
+    re[2][1] = alphas * M[0] * ch * ch;
+    re[2][5] = le[2][5] * M[0];
+    re[2][6] = le[2][6] * M[0];
+    re[3][0] = 1.0;
+    // positive-going waves: velocity entries change sign for S and F, field entries for A
+#pragma unroll
+    for (int pair = 0; pair < 3; pair++) {
+      const int n = pair, q = 6 - pair;
+      const double sv = (pair == 1) ? 1.0 : -1.0, sb = (pair == 1) ? -1.0 : 1.0;
+      le[q][2] = sv * le[n][2];
+      le[q][3] = sv * le[n][3];
+      le[q][4] = sv * le[n][4];
+      le[q][1] = le[n][1];
+      le[q][5] = sb * le[n][5];
+      le[q][6] = sb * le[n][6];
+      re[q][0] = re[n][0];
+      re[q][2] = sv * re[n][2];
+      re[q][3] = sv * re[n][3];
+      re[q][4] = sv * re[n][4];
+      re[q][1] = re[n][1];
+      re[q][5] = sb * re[n][5];
+      re[q][6] = sb * re[n][6];
+    }
+    const double a22 = 1. / (2. * ch * ch);
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+      le[0][j] *= a22;
+      le[2][j] *= a22;
+      le[4][j] *= a22;
+      le[6][j] *= a22;
+    }
+    double pd[7], str[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++) pd[j] = R[j] - L[j];
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < 7; j++) t += le[w][j] * pd[j];
+      str[w] = t;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) star[j] = L[j];
+    bool go = true;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      go = go && (ev[i] < 0.);
+      if (go) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) star[j] += str[i] * re[i][j];
+      }
+    }
+    if (fabs(M[2]) < (1.e-4 * ch)) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) pd[j] = R[j];
+      go = true;
+#pragma unroll
+      for (int i = 6; i >= 0; i--) {
+        go = go && (ev[i] > 0.);
+        if (go) {
+#pragma unroll
+          for (int j = 0; j < 7; j++) pd[j] -= str[i] * re[i][j];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 7; v++) star[v] = 0.5 * (star[v] + pd[v]);
+    }
+    if (star[1] < 0.) star[1] = c.refPG * PION_BASEPG;
+    if (star[0] < 0.) star[0] = c.refRO * PION_BASEPG;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ans[map[i]] = star[i];
+  }
+
+  // ------------------------------------------------------------------ Roe-MHD (conserved variables)
+  // Riemann_Roe_MHD_CV::MHD_Roe_CV_flux_solver_symmetric (Roe_MHD_ConservedVar_solver.cpp:218-264;
+  // Cargo & Gallice 1997, Stone+ 2009 eq. 65): average :345-405, differences :417-462, speeds
+  // :473-551, eigenvalues + H-correction :563-607, strengths :615-686, right eigenvectors :699-821,
+  // symmetric flux :1074-1133, P* from the mean state :299-331.
+  static PDEV void roe_mhd(const double *left, const double *right, const double g, const double hc_etamax,
+                           double *out_pstar, double *out_flux)
+  {
+    double UL[8], UR[8];
+    E::mhd_PtoU(left, UL, g);
+    E::mhd_PtoU(right, UR, g);
+    double mp[8];
+    const double rl = sqrt(left[qRO]), rr = sqrt(right[qRO]);
+    const double lH = ((left[qRO] * (left[qVN] * left[qVN] + left[qVT1] * left[qVT1] + left[qVT2] * left[qVT2]) / 2.0 +
+                        (g * left[qPG] / (g - 1.0)) +
+                        (left[qBN] * left[qBN] + left[qBT1] * left[qBT1] + left[qBT2] * left[qBT2])) /
+                       left[qRO]);
+    const double rH =
+        ((right[qRO] * (right[qVN] * right[qVN] + right[qVT1] * right[qVT1] + right[qVT2] * right[qVT2]) / 2.0 +
+          (g * right[qPG] / (g - 1.0)) +
+          (right[qBN] * right[qBN] + right[qBT1] * right[qBT1] + right[qBT2] * right[qBT2])) /
+         right[qRO]);
+    const double denom = 1.0 / (rl + rr);
+    mp[qRO] = rl * rr;
+    mp[qVN] = (rl * left[qVN] + rr * right[qVN]) * denom;
+    mp[qVT1] = (rl * left[qVT1] + rr * right[qVT1]) * denom;
+    mp[qVT2] = (rl * left[qVT2] + rr * right[qVT2]) * denom;
+    mp[qBT1] = (rr * left[qBT1] + rl * right[qBT1]) * denom;
+    mp[qBT2] = (rr * left[qBT2] + rl * right[qBT2]) * denom;
+    mp[qBN] = 0.5 * (left[qBN] + right[qBN]);
+    const int sgn = (mp[qBN] >= 0.0) ? 1 : -1;
+    const double HH = (rl * lH + rr * rH) * denom;  // enthalpy (kept in the pressure slot by the reference)
+    const double V = sqrt(mp[qVN] * mp[qVN] + mp[qVT1] * mp[qVT1] + mp[qVT2] * mp[qVT2]);
+    const double B = sqrt(mp[qBN] * mp[qBN] + mp[qBT1] * mp[qBT1] + mp[qBT2] * mp[qBT2]);
+    const double Bt = sqrt(mp[qBT1] * mp[qBT1] + mp[qBT2] * mp[qBT2]);
+    double by, bz;
+    if (Bt >= PION_TINYVALUE) {
+      by = mp[qBT1] / Bt;
+      bz = mp[qBT2] / Bt;
+    }
+    else {
+      by = 1.0 / sqrt(2.0);
+      bz = 1.0 / sqrt(2.0);
+    }
+    double ud[8], pd[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      ud[v] = UR[v] - UL[v];
+      pd[v] = right[v] - left[v];
+    }
+    ud[uBN] = pd[qBN] = 0.0;
+    const double X = (pd[qBT1] * pd[qBT1] + pd[qBT2] * pd[qBT2]) * 0.5 * denom * denom;
+    pd[qPG] = ((0.5 * V * V - X) * pd[qRO] - (mp[qVN] * ud[uMN] + mp[qVT1] * ud[uMT1] + mp[qVT2] * ud[uMT2]) +
+               ud[uERG] - (mp[qBT1] * pd[qBT1] + mp[qBT2] * pd[qBT2])) *
+              (g - 1.0);
+    const double b2 = B * B / mp[qRO];
+    const double a = sqrt((2.0 - g) * X + (g - 1.0) * dmax((HH - 0.5 * V * V - b2), 1.0e-12 * V * V));
+    const double astar2 = a * a + b2;
+    double ca = sqrt(mp[qBN] * mp[qBN] / mp[qRO]);
+    double cs = astar2 * astar2 - 4.0 * a * a * ca * ca;
+    if (cs <= 0.0) cs = 0.0;
+    else cs = sqrt(cs);
+    const double cf = sqrt(0.5 * (astar2 + cs));
+    cs = astar2 - cs;
+    if (cs <= 0.0) cs = 0.0;
+    else cs = sqrt(0.5 * cs);
+    if (ca > cf) ca = cf;
+    if (cs > ca) cs = ca;
+    double af, as, cf2diff;
+    if ((cf2diff = cf * cf - cs * cs) > PION_MACHINEACCURACY) {
+      if ((af = a * a - cs * cs) < 0.0) af = 0.;
+      if ((as = cf * cf - a * a) < 0.0) as = 0.;
+      if ((af = sqrt(af / cf2diff)) > 1.0) af = 1.0;
+      if ((as = sqrt(as / cf2diff)) > 1.0) as = 1.0;
+    }
+    else af = as = 1.0 / sqrt(2.0);
+    double ev[7] = {mp[qVN] - cf, mp[qVN] - ca, mp[qVN] - cs, mp[qVN], mp[qVN] + cs, mp[qVN] + ca, mp[qVN] + cf};
+#pragma unroll
+    for (int v = 0; v < 7; v++) {
+      if (ev[v] < 0.0) ev[v] = dmin(ev[v], -hc_etamax);
+      else ev[v] = dmax(ev[v], hc_etamax);
+    }
+    double st[7];
+    const double ro = mp[qRO], sro = sqrt(mp[qRO]);
+    st[0] = 0.5 * (af * (X * pd[qRO] + pd[qPG]) + ro * as * cs * sgn * (by * pd[qVT1] + bz * pd[qVT2]) -
+                   ro * af * cf * pd[qVN] + sro * as * a * (by * pd[qBT1] + bz * pd[qBT2]));
+    st[6] = 0.5 * (af * (X * pd[qRO] + pd[qPG]) - ro * as * cs * sgn * (by * pd[qVT1] + bz * pd[qVT2]) +
+                   ro * af * cf * pd[qVN] + sro * as * a * (by * pd[qBT1] + bz * pd[qBT2]));
+    st[2] = 0.5 * (as * (X * pd[qRO] + pd[qPG]) - ro * af * cf * sgn * (by * pd[qVT1] + bz * pd[qVT2]) -
+                   ro * as * cs * pd[qVN] - sro * af * a * (by * pd[qBT1] + bz * pd[qBT2]));
+    st[4] = 0.5 * (as * (X * pd[qRO] + pd[qPG]) + ro * af * cf * sgn * (by * pd[qVT1] + bz * pd[qVT2]) +
+                   ro * as * cs * pd[qVN] - sro * af * a * (by * pd[qBT1] + bz * pd[qBT2]));
+    st[1] = 0.5 * (+by * pd[qVT2] - bz * pd[qVT1] + sgn * (by * pd[qBT2] - bz * pd[qBT1]) / sro);
+    st[5] = 0.5 * (-by * pd[qVT2] + bz * pd[qVT1] + sgn * (by * pd[qBT2] - bz * pd[qBT1]) / sro);
+    st[3] = (a * a - X) * pd[qRO] - pd[qPG];
+    // right eigenvectors; columns: rho, m_n, m_t1, m_t2, B_t1, B_t2, E
+    double re[7][7];
+    re[3][0] = 1;
+    re[3][1] = mp[qVN];
+    re[3][2] = mp[qVT1];
+    re[3][3] = mp[qVT2];
+    re[3][4] = 0.0;
+    re[3][5] = 0.0;
+    re[3][6] = 0.5 * V * V + X * (g - 2) / (g - 1);
+#pragma unroll
+    for (int v = 0; v < 7; v++) re[3][v] /= a * a;
+    re[1][0] = 0.0;
+    re[1][1] = 0.0;
+    re[1][2] = -ro * bz;
+    re[1][3] = +ro * by;
+    re[1][4] = -sgn * sro * bz;
+    re[1][5] = +sgn * sro * by;
+    re[1][6] = -ro * (mp[qVT1] * bz - mp[qVT2] * by);
+    re[5][0] = 0.0;
+    re[5][1] = 0.0;
+    re[5][2] = -re[1][2];
+    re[5][3] = -re[1][3];
+    re[5][4] = re[1][4];
+    re[5][5] = re[1][5];
+    re[5][6] = -re[1][6];
+    const double das = ro * as, daf = ro * af;
+    re[2][0] = das;
+    re[2][1] = das * (mp[qVN] - cs);
+    re[2][2] = das * mp[qVT1] - daf * cf * by * sgn;
+    re[2][3] = das * mp[qVT2] - daf * cf * bz * sgn;
+    re[2][4] = -sro * af * a * by;
+    re[2][5] = -sro * af * a * bz;
+    re[2][6] = das * (HH - B * B / ro - mp[qVN] * cs) - daf * cf * sgn * (mp[qVT1] * by + mp[qVT2] * bz) -
+               sro * af * a * Bt;
+    re[4][0] = das;
+    re[4][1] = das * (mp[qVN] + cs);
+    re[4][2] = das * mp[qVT1] + daf * cf * by * sgn;
+    re[4][3] = das * mp[qVT2] + daf * cf * bz * sgn;
+    re[4][4] = re[2][4];
+    re[4][5] = re[2][5];
+    re[4][6] = das * (HH - B * B / ro + mp[qVN] * cs) + daf * cf * sgn * (mp[qVT1] * by + mp[qVT2] * bz) -
+               sro * af * a * Bt;
+    re[0][0] = daf;
+    re[0][1] = daf * (mp[qVN] - cf);
+    re[0][2] = daf * mp[qVT1] + das * cs * by * sgn;
+    re[0][3] = daf * mp[qVT2] + das * cs * bz * sgn;
+    re[0][4] = sro * as * a * by;
+    re[0][5] = sro * as * a * bz;
+    re[0][6] = daf * (HH - B * B / ro - mp[qVN] * cf) + das * cs * sgn * (mp[qVT1] * by + mp[qVT2] * bz) +
+               sro * as * a * Bt;
+    re[6][0] = daf;
+    re[6][1] = daf * (mp[qVN] + cf);
+    re[6][2] = daf * mp[qVT1] - das * cs * by * sgn;
+    re[6][3] = daf * mp[qVT2] - das * cs * bz * sgn;
+    re[6][4] = re[0][4];
+    re[6][5] = re[0][5];
+    re[6][6] = daf * (HH - B * B / ro + mp[qVN] * cf) - das * cs * sgn * (mp[qVT1] * by + mp[qVT2] * bz) +
+               sro * as * a * Bt;
+    const double norm = ro * a * a;
+#pragma unroll
+    for (int v = 0; v < 7; v++) {
+      re[2][v] /= norm;
+      re[4][v] /= norm;
+      re[0][v] /= norm;
+      re[6][v] /= norm;
+    }
+    double FR[8];
+    E::mhd_PUtoFlux(left, UL, out_flux);
+    E::mhd_PUtoFlux(right, UR, FR);
+#pragma unroll
+    for (int v = 0; v < 8; v++) out_flux[v] += FR[v];
+    constexpr int col[7] = {uRHO, uMN, uMT1, uMT2, uBT1, uBT2, uERG};
+#pragma unroll
+    for (int w = 0; w < 7; w++) {
+#pragma unroll
+      for (int cc = 0; cc < 7; cc++) out_flux[col[cc]] -= st[w] * fabs(ev[w]) * re[w][cc];
+    }
+#pragma unroll
+    for (int v = 0; v < 8; v++) out_flux[v] *= 0.5;
+#pragma unroll
+    for (int v = 0; v < NV; v++) out_pstar[v] = 0.0;  // Roe_meanp entries > 7 are never written
+#pragma unroll
+    for (int v = 0; v < 8; v++) out_pstar[v] = mp[v];
+    out_pstar[qPG] = out_pstar[qRO] * a * a / g;
+  }
+
   // ------------------------------------------------------------------ dispatch
   // hydro: solver_eqn_hydro_adi.cpp:94-201; ideal MHD: solver_eqn_mhd_adi.cpp:102-200
   static PDEV void inviscid_ideal(const double *Pl, const double *Pr, double *flux, double *pstar, const FluxCtx &c,
@@ -856,6 +1224,14 @@ struct Flux {
         for (int t = 0; t < NTR; t++) ustar[BASE + t] = 0.0;
         E::UtoP(ustar, pstar, c.min_temp, g, c.mp, err);
       }
+    }
+    else if constexpr (SOLVER == FLUX_RSroe) {
+      // (the reference's FKJ98 fallback needs err != 0, which the Roe solver never returns)
+      roe_mhd(Pl, Pr, g, hc_eta, pstar, flux);
+    }
+    else if constexpr (SOLVER == FLUX_RSlinear) {
+      jm_mhd_linear(Pl, Pr, pstar, c, err);
+      E::PtoFlux(pstar, flux, g);
     }
     else {
       double ustar[NV];

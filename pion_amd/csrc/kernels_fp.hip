@@ -386,6 +386,8 @@ static int flux_go(const FluxTestArgs &a, hipStream_t s)
 #define PION_SOLVER_CASES_MHD(FN, EQ, NTR, A, S)         \
   switch (A.solver) {                                    \
     case 0: return FN<EQ, NTR, 0>(A, S);                 \
+    case 1: return FN<EQ, NTR, 1>(A, S);                 \
+    case 4: return FN<EQ, NTR, 4>(A, S);                 \
     case 7: return FN<EQ, NTR, 7>(A, S);                 \
     case 8: return FN<EQ, NTR, 8>(A, S);                 \
     default: return -1;                                  \

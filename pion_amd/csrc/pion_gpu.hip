@@ -259,6 +259,7 @@ FluxCtx make_fluxctx(const Handle *h, double fv_dt)
   fc.refRO = h->refvec_avg[0];
   fc.refPG = h->refvec_avg[1];
   fc.refV = h->refvec_avg[2];
+  fc.refB = h->refvec_avg[5];
   fc.gndim = h->cfg.ndim;
   fc.artvisc = h->cfg.artvisc;
   fc.mp.present = (h->cfg.cooling != 0);
@@ -272,11 +273,12 @@ int check_errword(Handle *h)
   HCHECK(h, hipMemcpyAsync(&e, h->derr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   if (e) {
-    char b[256];
-    snprintf(b, sizeof b, "device physics error word 0x%x:%s%s%s%s", e,
+    char b[400];
+    snprintf(b, sizeof b, "device physics error word 0x%x:%s%s%s%s%s", e,
              (e & ERR_NEG_DENSITY) ? " negative density (reference: rep.error -> exit)" : "",
              (e & ERR_RIEMANN_INPUT) ? " density/pressure too small in Riemann solver" : "",
-             (e & ERR_COOLING) ? " cooling integration failed" : "", (e & ERR_BAD_DT) ? " invalid cell timestep" : "");
+             (e & ERR_COOLING) ? " cooling integration failed" : "", (e & ERR_BAD_DT) ? " invalid cell timestep" : "",
+             (e & ERR_MHD_RIEMANN) ? " linear MHD Riemann solver: bad wave speeds (reference: rep.error -> exit)" : "");
     h->err = b;
     int z = 0;
     hipMemcpyAsync(h->derr, &z, sizeof(int), hipMemcpyHostToDevice, h->stream);
@@ -301,7 +303,9 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (cfg->eqntype == PION_EQEUL) {
     if (cfg->solver == 7 || cfg->solver < 0 || cfg->solver > 8) return PION_GPU_EINVAL;
   }
-  else if (!(cfg->solver == 0 || cfg->solver == 7 || cfg->solver == 8)) return PION_GPU_EINVAL;
+  // MHD: LF, FKJ98 linear, Roe, HLLD, HLL (exact/hybrid are fatal in riemannMHD.cpp:176-181)
+  else if (!(cfg->solver == 0 || cfg->solver == 1 || cfg->solver == 4 || cfg->solver == 7 || cfg->solver == 8))
+    return PION_GPU_EINVAL;
   if (cfg->cooling != 0 && cfg->cooling != PION_COOL_WSS09_CIE_LINE_HEAT_COOL) return PION_GPU_EINVAL;
 
   Handle *h = new Handle;
@@ -403,6 +407,41 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (cfg->eqntype == PION_EQEUL) {
     const double refvel = sqrt(cfg->gamma * cfg->refvec[1] / cfg->refvec[0]);
     h->refvec_avg[2] = h->refvec_avg[3] = h->refvec_avg[4] = 0.1 * refvel;
+  }
+  else {
+    // eqns_mhd_ideal::SetAvgState (eqns_mhd_adiabatic.cpp:501-544): fast speed of the reference
+    // state with the field rotated into the x-y plane's x axis; velocities <- 0.1 c_f, fields <- |B|
+    double *rv = h->refvec_avg;
+    const double gam = cfg->gamma;
+    auto cfast = [&](const double *p) {
+      const double ch = sqrt(gam * p[1] / p[0]);
+      const double t1 = ch * ch + (p[5] * p[5] + p[6] * p[6] + p[7] * p[7]) / p[0];
+      double t2 = 4. * ch * ch * p[5] * p[5] / p[0];
+      t2 = std::max(5.e-16, t1 * t1 - t2);
+      return sqrt((t1 + sqrt(t2)) / 2.);
+    };
+    auto rotate_xy = [&](double *v, double theta) {
+      const double ct = cos(theta), st = sin(theta);
+      double a = v[2] * ct - v[3] * st, b = v[2] * st + v[3] * ct;
+      v[2] = a;
+      v[3] = b;
+      a = v[5] * ct - v[6] * st;
+      b = v[5] * st + v[6] * ct;
+      v[5] = a;
+      v[6] = b;
+    };
+    double angle = rv[6] * rv[6] + rv[5] * rv[5], refvel;
+    if (angle > 10. * 5.e-16) {
+      angle = M_PI / 2. - asin(rv[6] / sqrt(angle));
+      if (rv[5] < 0) angle = -angle;
+      rotate_xy(rv, angle);
+      refvel = cfast(rv);
+      rotate_xy(rv, -angle);
+    }
+    else refvel = cfast(rv);
+    const double refB = sqrt(rv[5] * rv[5] + rv[6] * rv[6] + rv[7] * rv[7]);
+    rv[2] = rv[3] = rv[4] = 0.1 * refvel;
+    rv[5] = rv[6] = rv[7] = refB;
   }
   for (int d = 0; d < 6; d++)
     for (int v = 0; v < PION_MAX_NVAR; v++) h->refval[d][v] = 0.0;

@@ -11,6 +11,10 @@ Fixtures are data: seeded inputs and the reference's outputs, stored as compress
                      MHD and GLM-MHD: LF, HLL, HLLD incl. the HLL switch), with and without
                     tracers and FKJ98 viscosity, along all three axes, 160 state pairs each
                     including degenerate pairs (equal states, Bx=0, Bt=0, supersonic, vacuum).
+  flux_kat_b.npz    the same for the Roe-MHD solver (with and without the H-correction eta) and the
+                    FKJ98 linear MHD solver, ideal and GLM-MHD (own seed; `make_golden.py b`).
+  steps_b.npz       whole-grid dumps for ideal-MHD Roe + H-correction 2-D, GLM-MHD Roe 3-D, GLM-MHD
+                    linear solver 2-D with mixed boundaries.
   cell_kat.npz      CellAdvanceTime and CellTimeStep vectors (incl. negative-pressure repair,
                     with and without a microphysics object).
   steps.npz         whole-grid dumps after 2 second-order steps (and per-stage aux data) for small

@@ -196,7 +196,7 @@ def test_every_hd_instantiation_3d(solver, ntr, strict, monkeypatch):
 
 @pytest.mark.parametrize("strict", [1, 0])
 @pytest.mark.parametrize("ntr", [0, 1, 2])
-@pytest.mark.parametrize("solver", [0, 7, 8])
+@pytest.mark.parametrize("solver", [0, 1, 4, 7, 8])
 @pytest.mark.parametrize("eq", [abi.EQMHD, abi.EQGLM])
 def test_every_mhd_instantiation_3d(eq, solver, ntr, strict, monkeypatch):
     cfg0, P0 = problems.mhd_blastwave(14, 3, eq, solver, strict_fp=strict)
