@@ -27,15 +27,11 @@ from pion_amd import abi, driver, lib, problems, slab  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(n, eqntype, solver, budget_s=15.0):
-    """CPU 'port' baseline: the scalar oracle (oracle/liboracle.so, single thread) on the same
-    problem shrunk to n^3, timed for a bounded number of steps."""
+def _time_cpu(kind, n, eqntype, solver, budget_s):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from cpu_backends import CpuSim, have_oracle
-    if not have_oracle():
-        return None
+    from cpu_backends import CpuSim
     cfg, P = problems.mhd_blastwave(n, 3, eqntype, solver, strict_fp=1)
-    with CpuSim(cfg, "orc") as o:
+    with CpuSim(cfg, kind) as o:
         sc = driver.SimControl(o, cfg)
         sc.init(P)
         sc.calculate_timestep()
@@ -49,9 +45,32 @@ def cpu_baseline(n, eqntype, solver, budget_s=15.0):
             el = time.perf_counter() - t0
             if el > budget_s or steps >= 50:
                 break
-    return {"value": n ** 3 * steps / el / 1e6, "unit": "Mcell-updates/s", "cores": 1, "kind": "port",
-            "sample": "%d steps of the same GLM-MHD HLLD blast on %d^3 (%.1f s, 1 thread, oracle/liboracle.so)"
-                      % (steps, n, el)}
+    return n ** 3 * steps / el / 1e6, steps, el
+
+
+def cpu_baseline(n, eqntype, solver, budget_s=12.0):
+    """CPU baseline on the same problem shrunk to n^3, one thread, a bounded number of steps.
+    kind "reference": oracle/_ref/libpion_ref.so -- the reference's own solver objects (compiled from
+    /root/reference in the build container by `make -C oracle ref`; the .so travels with the snapshot)
+    driven by oracle/ref_harness.cpp's restatement of the time_integrator loops -- when it is present;
+    otherwise kind "port": the scalar oracle (oracle/liboracle.so).  The other one is reported beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cpu_backends import have_oracle, have_ref
+    res = {}
+    if have_ref():
+        res["reference"] = _time_cpu("ref", n, eqntype, solver, budget_s)
+    if have_oracle():
+        res["port"] = _time_cpu("orc", n, eqntype, solver, budget_s)
+    if not res:
+        return None
+    kind = "reference" if "reference" in res else "port"
+    v, steps, el = res[kind]
+    lib = "oracle/_ref/libpion_ref.so (reference objects, -O3 -DSERIAL)" if kind == "reference" else "oracle/liboracle.so"
+    out = {"value": v, "unit": "Mcell-updates/s", "cores": 1, "kind": kind,
+           "sample": "%d steps of the same GLM-MHD HLLD blast on %d^3 (%.1f s, 1 thread, %s)" % (steps, n, el, lib)}
+    if kind == "reference" and "port" in res:
+        out["port_value"] = res["port"][0]
+    return out
 
 
 def main():
@@ -154,7 +173,8 @@ def main():
                        "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world,
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
                          "kernel": "k_stage_rows<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows<MHD,0,HLLD>",
                          "kernel_ms": stage_ms, "launches_per_stage": tm["stage_n"] / (2.0 * args.steps), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes},
