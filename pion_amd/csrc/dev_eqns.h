@@ -132,11 +132,20 @@ struct Eqn {
   static PDEV double cfast_components(const double cfRO, const double cfPG, const double cfBX, const double cfBY,
                                       const double cfBZ, const double g)
   {
+#ifdef PION_FAST_MATH
+    // fast build: a^2 = gamma p / rho directly (the strict form squares its square root), one reciprocal
+    const double ir = 1.0 / cfRO;
+    const double a2 = g * cfPG * ir;
+    const double temp1 = a2 + (cfBX * cfBX + cfBY * cfBY + cfBZ * cfBZ) * ir;
+    const double temp2 = dmax(PION_MACHINEACCURACY, temp1 * temp1 - 4. * a2 * cfBX * cfBX * ir);
+    return (sqrt((temp1 + sqrt(temp2)) * 0.5));
+#else
     double ch = sqrt(g * cfPG / cfRO);
     double temp1 = ch * ch + (cfBX * cfBX + cfBY * cfBY + cfBZ * cfBZ) / cfRO;
     double temp2 = 4. * ch * ch * cfBX * cfBX / cfRO;
     temp2 = dmax(PION_MACHINEACCURACY, temp1 * temp1 - temp2);
     return (sqrt((temp1 + sqrt(temp2)) / 2.));
+#endif
   }
   static PDEV void mhd_PUtoFlux(const double *p, const double *u, double *f)
   {

@@ -682,6 +682,125 @@ struct Flux {
       }
     }
   }
+#ifdef PION_FAST_MATH
+  // Fast-build HLLD (Miyoshi & Kusano 2005): the same solver as the strict function below, evaluated
+  // one-sided.  The strict form (the reference's, HLLD_MHD.cpp:124-333) builds U, F, U*, U** for BOTH
+  // sides and then picks one of six regions; here the region is decided first (same comparisons, same
+  // order), the side K is selected, and only F_K, U_K, U*_K, U**_K are built:
+  //     F = F_K + [region>=1] S_K (U*_K - U_K) + [region==2] S*_K (U**_K - U*_K),
+  // which is the reference's expression regrouped (exact in real arithmetic, differs by rounding).
+  // Reciprocals are shared and a^2 = gamma p/rho is used where the strict form squares sqrt(a^2).
+  static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar)
+  {
+    const double BX = 0.5 * (Pl[qBN] + Pr[qBN]);
+    const double BX2 = BX * BX;
+    const double irl = 1.0 / Pl[qRO], irr = 1.0 / Pr[qRO];
+    // HLLD_signal_speeds with B_n := BX
+    double cfm;
+    {
+      const double a2l = g * Pl[qPG] * irl, a2r = g * Pr[qPG] * irr;
+      const double t1l = a2l + (BX2 + Pl[qBT1] * Pl[qBT1] + Pl[qBT2] * Pl[qBT2]) * irl;
+      const double t1r = a2r + (BX2 + Pr[qBT1] * Pr[qBT1] + Pr[qBT2] * Pr[qBT2]) * irr;
+      const double t2l = dmax(PION_MACHINEACCURACY, t1l * t1l - 4. * a2l * BX2 * irl);
+      const double t2r = dmax(PION_MACHINEACCURACY, t1r * t1r - 4. * a2r * BX2 * irr);
+      cfm = dmax(sqrt((t1l + sqrt(t2l)) * 0.5), sqrt((t1r + sqrt(t2r)) * 0.5));
+    }
+    const double SL = dmin(Pl[qVN], Pr[qVN]) - cfm, SR = dmax(Pl[qVN], Pr[qVN]) + cfm;
+    const double sl_vl = SL - Pl[qVN], sr_vr = SR - Pr[qVN];
+    const double ptl = E::mhd_Ptot(Pl), ptr = E::mhd_Ptot(Pr);
+    const double rsl = Pl[qRO] * sl_vl, rsr = Pr[qRO] * sr_vr;
+    const double itemp = 1.0 / (rsr - rsl);
+    const double SM = (rsr * Pr[qVN] - rsl * Pl[qVN] - ptr + ptl) * itemp;
+    const double pts = (rsr * ptl - rsl * ptr + rsl * rsr * (Pr[qVN] - Pl[qVN])) * itemp;
+    const double sl_sm = SL - SM, sr_sm = SR - SM;
+    const double rosl = rsl / sl_sm, rosr = rsr / sr_sm;
+    // tangential velocity and field behind the fast waves, both sides (the ** state needs both)
+    double vys_l = Pl[qVT1], vzs_l = Pl[qVT2], bys_l = 0.0, bzs_l = 0.0;
+    double vys_r = Pr[qVT1], vzs_r = Pr[qVT2], bys_r = 0.0, bzs_r = 0.0;
+    {
+      const double den = 1.0 / (rsl * sl_sm - BX2);
+      const double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
+      if (isfinite(q1)) {
+        vys_l = Pl[qVT1] - BX * Pl[qBT1] * q1;
+        vzs_l = Pl[qVT2] - BX * Pl[qBT2] * q1;
+      }
+      if (isfinite(q2)) {
+        bys_l = Pl[qBT1] * q2;
+        bzs_l = Pl[qBT2] * q2;
+      }
+    }
+    {
+      const double den = 1.0 / (rsr * sr_sm - BX2);
+      const double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
+      if (isfinite(q1)) {
+        vys_r = Pr[qVT1] - BX * Pr[qBT1] * q1;
+        vzs_r = Pr[qVT2] - BX * Pr[qBT2] * q1;
+      }
+      if (isfinite(q2)) {
+        bys_r = Pr[qBT1] * q2;
+        bzs_r = Pr[qBT2] * q2;
+      }
+    }
+    const double sql = sqrt(rosl), sqr = sqrt(rosr);
+    const double aBX = fabs(BX);
+    const double SsL = SM - aBX / sql, SsR = SM + aBX / sqr;
+    // Alfven-averaged state
+    const double sgn = (double)((BX > 0) - (BX < 0));
+    const double isum = 1.0 / (sql + sqr);
+    const double vy_ss = (sql * vys_l + sqr * vys_r + (bys_r - bys_l) * sgn) * isum;
+    const double vz_ss = (sql * vzs_l + sqr * vzs_r + (bzs_r - bzs_l) * sgn) * isum;
+    const double by_ss = (sql * bys_r + sqr * bys_l + sql * sqr * (vys_r - vys_l) * sgn) * isum;
+    const double bz_ss = (sql * bzs_r + sqr * bzs_l + sql * sqr * (vzs_r - vzs_l) * sgn) * isum;
+    // region, decided in the reference's order (a NaN speed falls through exactly as there)
+    const bool r0L = (SL > 0);
+    const bool r1L = !r0L && (SsL >= 0);
+    const bool r2L = !r0L && !r1L && (SM >= 0);
+    const bool left = r0L || r1L || r2L;
+    const bool r2R = !left && (SsR >= 0);
+    const bool r1R = !left && !r2R && (SR >= 0);
+    const bool w1 = r1L || r2L || r2R || r1R;
+    const bool w2 = (r2L || r2R) && (BX != 0);  // B_n = 0: U** = U* (and the region is unreachable)
+    // everything of side K
+    double PK[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) PK[v] = left ? Pl[v] : Pr[v];
+    const double SK = left ? SL : SR, SsK = left ? SsL : SsR;
+    const double sK_vK = left ? sl_vl : sr_vr, isK_sm = 1.0 / (left ? sl_sm : sr_sm);
+    const double rosK = left ? rosl : rosr, sqK = left ? sql : sqr, ptK = left ? ptl : ptr;
+    const double vysK = left ? vys_l : vys_r, vzsK = left ? vzs_l : vzs_r;
+    const double bysK = left ? bys_l : bys_r, bzsK = left ? bzs_l : bzs_r;
+    double UK[8], FK[8];
+    E::mhd_PtoU(PK, UK, g);
+    E::mhd_PUtoFlux(PK, UK, FK);
+    const double vBK = PK[qVN] * BX + PK[qVT1] * PK[qBT1] + PK[qVT2] * PK[qBT2];
+    const double vBs = SM * BX + vysK * bysK + vzsK * bzsK;
+    double Us[8], Uss[8];
+    Us[uRHO] = rosK;
+    Us[uMN] = SM * rosK;
+    Us[uMT1] = vysK * rosK;
+    Us[uMT2] = vzsK * rosK;
+    Us[uBN] = BX;
+    Us[uBT1] = bysK;
+    Us[uBT2] = bzsK;
+    Us[uERG] = (sK_vK * UK[uERG] - ptK * PK[qVN] + pts * SM + BX * (vBK - vBs)) * isK_sm;
+    const double vBss = SM * BX + vy_ss * by_ss + vz_ss * bz_ss;
+    Uss[uRHO] = rosK;
+    Uss[uMN] = Us[uMN];
+    Uss[uMT1] = vy_ss * rosK;
+    Uss[uMT2] = vz_ss * rosK;
+    Uss[uBN] = BX;
+    Uss[uBT1] = by_ss;
+    Uss[uBT2] = bz_ss;
+    Uss[uERG] = left ? Us[uERG] - sqK * (vBs - vBss) * sgn : Us[uERG] + sqK * (vBs - vBss) * sgn;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      const double d1 = Us[v] - UK[v], d2 = Uss[v] - Us[v];
+      const double a1 = w1 ? SK * d1 : 0.0, a2 = w2 ? SsK * d2 : 0.0;
+      out_flux[v] = FK[v] + a1 + a2;
+      out_ustar[v] = (r2L || r2R) ? (w2 ? Uss[v] : Us[v]) : (w1 ? Us[v] : UK[v]);
+    }
+  }
+#else
   static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar)
   {
     double UL[8], UR[8], FL[8], FR[8], ULs[8], URs[8], ULss[8], URss[8], lam[5];
@@ -819,6 +938,8 @@ struct Flux {
       }
     }
   }
+
+#endif  // PION_FAST_MATH
 
   // ------------------------------------------------------------------ FKJ98 linear MHD solver
   // riemann_MHD::JMs_riemann_solve (riemannMHD.cpp:165-405) with the Roe-Balsara eigenvectors

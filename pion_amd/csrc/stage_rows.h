@@ -17,8 +17,11 @@
 #ifndef PION_STAGE_ROWS_H
 #define PION_STAGE_ROWS_H
 
+#ifndef PION_ROWS_ATTR
+#define PION_ROWS_ATTR
+#endif
 template <int EQ, int NTR, int SOLVER>
-__global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
+__global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageArgs a)
 {
   typedef Eqn<EQ, NTR> E;
   typedef Flux<EQ, NTR, SOLVER> FX;
@@ -92,20 +95,35 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
 #pragma unroll 1
     for (int r = 0; r < nrows; r++) {
       const long c = crow0 + sy * r + sz * (k - (k0 - 1));
-      double q0[NV];
+      // Load order matters: a wavefront's loads return in order and only one wavefront runs per SIMD,
+      // so a wait for any load also waits for every older one.  First what the x task needs at once
+      // (L1/L2 hits: this row was a y neighbour of the previous one), THEN the loads that go to HBM and
+      // are not needed for a whole Riemann solve: the start-of-step state (used after the four tasks)
+      // and the farthest y row / z plane of the stencil (used by the y and z tasks) -- their latency
+      // is covered by the x and y flux computations.
+      double q0[NV], xqm[NV], xqp[NV];
 #pragma unroll
       for (int v = 0; v < NV; v++) q0[v] = a.S[v * nc + c];
+      if (!prime) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+          xqm[v] = a.S[v * nc + c - 1];
+          xqp[v] = a.S[v * nc + c + 1];
+        }
+      }
       double dU[NV];
 #pragma unroll
       for (int v = 0; v < NV; v++) dU[v] = 0.0;
-      // start-of-step state and flags of this cell: issued now, consumed after the four tasks
-      double P0[NV];
+      double P0[NV], yfar[NV], zfar[NV];
       uint8_t fl = 0;
+      const long far = oa2 ? 2 : 1;
       if (!prime) {
 #pragma unroll
         for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
         fl = a.flags[c];
+        load_rot<NV, MHD>(a.S, nc, 1, c + far * sy, yfar);
       }
+      load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
 
       if (!prime && a.cooling != 0) {
         if (fl & 4) {
@@ -134,12 +152,8 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
           ax = 0;
           st = 1;
           cl = c;
-          double qm[NV], qp[NV], sx[NV];
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            qm[v] = a.S[v * nc + c - 1];
-            qp[v] = a.S[v * nc + c + 1];
-          }
+          const double *qm = xqm, *qp = xqp;
+          double sx[NV];
           slope3<NV>(qm, q0, qp, dx, oa2, sx);
 #pragma unroll
           for (int v = 0; v < NV; v++) {
@@ -198,11 +212,17 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
           cl = c;
           double yq0[NV], qp1[NV], qp2[NV], sp[NV];
           to_sweep<NV, MHD>(1, q0, yq0);
-          load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
-          if (oa2) load_rot<NV, MHD>(a.S, nc, 1, c + 2 * sy, qp2);
+          if (oa2) {
+            load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp2[v] = yfar[v];
+          }
           else {
 #pragma unroll
-            for (int v = 0; v < NV; v++) qp2[v] = 0.0;
+            for (int v = 0; v < NV; v++) {
+              qp1[v] = yfar[v];
+              qp2[v] = 0.0;
+            }
           }
           if (r > 0) {
 #pragma unroll
@@ -237,11 +257,17 @@ __global__ __launch_bounds__(256) void k_stage_rows(const StageArgs a)
           cl = c;
           double zq0[NV], qp1[NV], qp2[NV], sn[NV];
           to_sweep<NV, MHD>(2, q0, zq0);
-          load_rot<NV, MHD>(a.S, nc, 2, c + sz, qp1);
-          if (oa2) load_rot<NV, MHD>(a.S, nc, 2, c + 2 * sz, qp2);
+          if (oa2) {
+            load_rot<NV, MHD>(a.S, nc, 2, c + sz, qp1);
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp2[v] = zfar[v];
+          }
           else {
 #pragma unroll
-            for (int v = 0; v < NV; v++) qp2[v] = 0.0;
+            for (int v = 0; v < NV; v++) {
+              qp1[v] = zfar[v];
+              qp2[v] = 0.0;
+            }
           }
           slope3<NV>(zq0, qp1, qp2, dx, oa2, sn);
 #pragma unroll
