@@ -28,6 +28,55 @@ struct BCArgs {
   double dmr_a0, dmr_t3;  // 10*simtime/sin(pi/3), tan(pi/3)  (host libm, as the reference)
 };
 
+// All periodic faces of a grid in ONE launch (the bench configuration).  The X -> Y -> Z sequence of
+// periodic copies (periodic_boundaries.cpp:42-50, corner cells through already filled ghosts) ends with
+// every ghost cell holding the on-grid cell at its coordinates wrapped axis by axis, so the wrapped
+// cell can be read directly: the same values, one launch instead of six.  z faces of kind SLAB
+// (neighbour rank) are left alone: then only ghosts on on-grid z planes are filled.
+__global__ __launch_bounds__(256) void k_bc_periodic_all(double *T, const GridDesc g, const int nvar, const int zwrap)
+{
+  // ghost cells as three disjoint slabs: A = z ghosts (all x,y), B = y ghosts on on-grid z (all x),
+  // C = x ghosts on on-grid y and z
+  const long nA = zwrap ? (long)2 * g.nbc[2] * g.nga[0] * g.nga[1] : 0;
+  const long nB = (long)g.ng[2] * 2 * g.nbc[1] * g.nga[0];
+  const long nC = (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nA + nB + nC) return;
+  int i0, i1, i2;  // all-cell coordinates (ghosts included)
+  if (t < nA) {
+    i0 = (int)(t % g.nga[0]);
+    i1 = (int)((t / g.nga[0]) % g.nga[1]);
+    const int kz = (int)(t / ((long)g.nga[0] * g.nga[1]));
+    i2 = (kz < g.nbc[2]) ? kz : g.ng[2] + kz;
+  }
+  else if (t < nA + nB) {
+    t -= nA;
+    i0 = (int)(t % g.nga[0]);
+    const int ky = (int)((t / g.nga[0]) % (2 * g.nbc[1]));
+    i1 = (ky < g.nbc[1]) ? ky : g.ng[1] + ky;
+    i2 = (int)(t / ((long)g.nga[0] * 2 * g.nbc[1])) + g.nbc[2];
+  }
+  else {
+    t -= nA + nB;
+    const int kx = (int)(t % (2 * g.nbc[0]));
+    i0 = (kx < g.nbc[0]) ? kx : g.ng[0] + kx;
+    i1 = (int)((t / (2 * g.nbc[0])) % g.ng[1]) + g.nbc[1];
+    i2 = (int)(t / ((long)2 * g.nbc[0] * g.ng[1])) + g.nbc[2];
+  }
+  // wrap each coordinate back onto the grid
+  int s0 = i0, s1 = i1, s2 = i2;
+  if (s0 < g.nbc[0]) s0 += g.ng[0];
+  else if (s0 >= g.nbc[0] + g.ng[0]) s0 -= g.ng[0];
+  if (s1 < g.nbc[1]) s1 += g.ng[1];
+  else if (s1 >= g.nbc[1] + g.ng[1]) s1 -= g.ng[1];
+  if (zwrap) {
+    if (s2 < g.nbc[2]) s2 += g.ng[2];
+    else if (s2 >= g.nbc[2] + g.ng[2]) s2 -= g.ng[2];
+  }
+  const long c = (long)i0 + g.sy * i1 + g.sz * i2, sc = (long)s0 + g.sy * s1 + g.sz * s2;
+  for (int v = 0; v < nvar; v++) T[v * g.ncell + c] = T[v * g.ncell + sc];
+}
+
 // One thread per ghost cell of one face.  List membership follows UniformGrid::SetupBCs
 // (grid/uniform_grid.cpp:1009-1216): X faces hold on-grid (y,z) rows only, Y faces the full x
 // extent, Z faces the full x-y extent, which together with the X->Y->Z launch order fills the
@@ -210,6 +259,7 @@ struct Handle {
   double Mu_tot_over_kB = 0.0;
   int use_march = 2, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
   bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
+  bool fuse_bc = true;    // PION_FUSE_BC=0: periodic faces one launch per face (A/B)
 };
 
 #define HCHECK(h, call)                                                            \
@@ -313,6 +363,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (const char *e = getenv("PION_STAGE_KERNEL"))
     h->use_march = (strcmp(e, "cell") == 0) ? 0 : ((strcmp(e, "march") == 0) ? 1 : 2);
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
+  if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
   if (const char *e = getenv("PION_ROWS")) h->rows = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
   if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 0;
   h->device = device;
@@ -622,8 +673,22 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
     hipLaunchKernelGGL(k_wind, dim3((unsigned)((h->nwind + 255) / 256)), dim3(256), 0, h->stream, T, h->dwind_idx,
                        h->dwind_state, h->nwind, cfg.nvar, g.ncell);
   }
+  // every face periodic (z possibly handed to the neighbour ranks): one launch fills all ghosts
+  bool all_periodic = (h->nwind == 0 && !cfg.bc_dmach2 && h->fuse_bc);
+  for (int d = 0; d < 2 * cfg.ndim && all_periodic; d++) {
+    const bool zface = (d >= 4);
+    if (!(cfg.bc_type[d] == PION_BC_PERIODIC || (zface && cfg.bc_type[d] == PION_BC_SLAB))) all_periodic = false;
+  }
+  if (all_periodic && cfg.ndim == 3 && cfg.bc_type[4] != cfg.bc_type[5]) all_periodic = false;
+  if (all_periodic) {
+    const int zwrap = (cfg.ndim == 3 && cfg.bc_type[4] == PION_BC_PERIODIC) ? 1 : 0;
+    const long n = (zwrap ? (long)2 * g.nbc[2] * g.nga[0] * g.nga[1] : 0) + (long)g.ng[2] * 2 * g.nbc[1] * g.nga[0]
+                   + (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
+    hipLaunchKernelGGL(k_bc_periodic_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, T, g, cfg.nvar,
+                       zwrap);
+  }
   // TimeUpdateExternalBCs in list order XN,XP,YN,YP,ZN,ZP then DMR2 (assign_update_bcs.cpp:185-252)
-  for (int d = 0; d < 2 * cfg.ndim; d++) {
+  for (int d = 0; d < 2 * cfg.ndim && !all_periodic; d++) {
     const int type = cfg.bc_type[d];
     if (type == 0 || type == PION_BC_SLAB) continue;
     if (assign) {
