@@ -78,11 +78,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=512, help="cells per axis (headline: 512)")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=512, help="cells per axis (headline: 512); use --grid under torch.distributed.run, whose own parser finds --n ambiguous")
     ap.add_argument("--eqn", default="glm", choices=["glm", "mhd"])
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-parity kernels (no FMA contraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=64)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
+                         "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,8 +103,13 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % torch.cuda.device_count()
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
 
     cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
     n = args.n
@@ -138,7 +146,7 @@ def main():
     el = time.perf_counter() - t0
     tm = sim.get_timing()
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -170,7 +178,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
                                    % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
-                       "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world,
+                       "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": "none" if world == 1 else
+                       ("RCCL P2P" if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"),
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,

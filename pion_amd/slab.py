@@ -60,7 +60,10 @@ class SlabComm:
     tensor on the device the backend computes on; backend.pack_halo/unpack_halo take
     (which, face, tensor.data_ptr())."""
 
-    def __init__(self, rank, world, periodic, halo_count, device):
+    def __init__(self, rank, world, periodic, halo_count, device, host_staged=None):
+        """host_staged: exchange through pinned host buffers (GPU state, CPU-only backend such as
+        gloo: rehearsals of the multi-rank GPU path on a box without RCCL peers).  Default: staged iff
+        the device is a GPU and the process group's backend is not nccl."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -69,9 +72,17 @@ class SlabComm:
         self.down = (rank - 1) % world if (periodic or rank > 0) else None
         if world == 1:
             self.up = self.down = None
+        device = torch.device(device)
         mk = lambda: torch.empty(halo_count, dtype=torch.float64, device=device)
         self.send_up, self.send_down, self.recv_up, self.recv_down = mk(), mk(), mk(), mk()
-        self.dtbuf = torch.empty(2, dtype=torch.float64, device=device)
+        if host_staged is None:
+            host_staged = (device.type == "cuda" and world > 1 and dist.is_initialized()
+                           and dist.get_backend() != "nccl")
+        self.host_staged = bool(host_staged)
+        if self.host_staged:
+            mkh = lambda: torch.empty(halo_count, dtype=torch.float64).pin_memory()
+            self.h_send_up, self.h_send_down, self.h_recv_up, self.h_recv_down = mkh(), mkh(), mkh(), mkh()
+        self.dtbuf = torch.empty(2, dtype=torch.float64, device="cpu" if self.host_staged else device)
         self.pending = None
         self.kstream = self.cstream = None
 
@@ -101,18 +112,29 @@ class SlabComm:
                 sim.pack_halo(which, 5, self.send_up.data_ptr())      # my top on-grid planes
             if self.down is not None:
                 sim.pack_halo(which, 4, self.send_down.data_ptr())    # my bottom on-grid planes
-            if self.cstream is None:
+            su, sd, ru, rd = self.send_up, self.send_down, self.recv_up, self.recv_down
+            if self.host_staged:
+                # pack ran on the comm stream (or, without streams, on the handle's stream)
+                if self.cstream is None:
+                    sim.synchronize()
+                if self.up is not None:
+                    self.h_send_up.copy_(self.send_up, non_blocking=True)
+                if self.down is not None:
+                    self.h_send_down.copy_(self.send_down, non_blocking=True)
+                self.torch.cuda.current_stream().synchronize()
+                su, sd, ru, rd = self.h_send_up, self.h_send_down, self.h_recv_up, self.h_recv_down
+            elif self.cstream is None:
                 sim.synchronize()
             # order matters when up == down (2 ranks, periodic): first message = "top" planes
             ops = []
             if self.up is not None:
-                ops.append(dist.P2POp(dist.isend, self.send_up, self.up))
+                ops.append(dist.P2POp(dist.isend, su, self.up))
             if self.down is not None:
-                ops.append(dist.P2POp(dist.irecv, self.recv_down, self.down))
+                ops.append(dist.P2POp(dist.irecv, rd, self.down))
             if self.down is not None:
-                ops.append(dist.P2POp(dist.isend, self.send_down, self.down))
+                ops.append(dist.P2POp(dist.isend, sd, self.down))
             if self.up is not None:
-                ops.append(dist.P2POp(dist.irecv, self.recv_up, self.up))
+                ops.append(dist.P2POp(dist.irecv, ru, self.up))
             self.pending = (which, dist.batch_isend_irecv(ops))
 
     def finish(self, sim):
@@ -123,8 +145,15 @@ class SlabComm:
         ctx = self.torch.cuda.stream(self.cstream) if self.cstream is not None else _nullctx()
         with ctx:
             for w in works:
-                w.wait()        # GPU: the comm stream waits for RCCL, the host does not
-            if self.cstream is None and self.recv_down.is_cuda:
+                w.wait()        # GPU + RCCL: the comm stream waits, the host does not
+            if self.host_staged:
+                if self.down is not None:
+                    self.recv_down.copy_(self.h_recv_down, non_blocking=True)
+                if self.up is not None:
+                    self.recv_up.copy_(self.h_recv_up, non_blocking=True)
+                if self.cstream is None:
+                    self.torch.cuda.current_stream().synchronize()
+            elif self.cstream is None and self.recv_down.is_cuda:
                 self.torch.cuda.current_stream().synchronize()
             if self.down is not None:
                 sim.unpack_halo(which, 4, self.recv_down.data_ptr())  # neighbour's top -> my ZN ghosts
