@@ -69,6 +69,7 @@ extern "C" {
 #define PION_BC_DMACH2 8  /* internal: fixed post-shock state in y<0, x<=1/6 */
 #define PION_BC_STWIND 9  /* internal: stellar-wind cells (fixed per-cell state) */
 #define PION_BC_SLAB 10   /* z face owned by a neighbouring GPU (halo exchange) */
+#define PION_BC_JET 11    /* internal: jet inflow cells on the XN face (pion_gpu_set_jet) */
 
 /* cooling functions of mp_only_cooling (microphysics/mp_only_cooling.h) */
 #define PION_COOL_NONE 0
@@ -155,6 +156,13 @@ int pion_gpu_synchronize(void *handle);
  * ghosts), states = n*nvar doubles (cell-major).  Marks the cells
  * isbd=true,isdomain=false (stellar_wind_BC.cpp:277-278). */
 int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double *states);
+
+/* jet_bc::BC_assign_JETBC / BC_update_JETBC (boundaries/jet_boundaries.cpp:36-208, 3-D Cartesian
+ * branch :170-201, update :212-262) with JetParams (sim_params.h:331-341): every XN ghost cell of an
+ * on-grid (y,z) column whose centre lies within jetradius*dx of the x axis holds `jetstate`
+ * (rho, p_g, v, then tracers), re-imposed after the external boundaries at every boundary update.
+ * 3-D Euler only, as in the reference (MHD jets there need 2-D cylindrical coordinates). */
+int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate);
 
 /* mp_only_cooling look-up tables (microphysics/mp_only_cooling.cpp:528-579):
  * nT temperatures, 5 value tables and 5 slope tables in the order

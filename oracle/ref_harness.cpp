@@ -40,6 +40,7 @@
 #include "boundaries/reflecting_boundaries.h"
 #include "boundaries/fixed_boundaries.h"
 #include "boundaries/double_Mach_ref_boundaries.h"
+#include "boundaries/jet_boundaries.h"
 
 #include "../include/pion_gpu.h"
 
@@ -314,7 +315,8 @@ struct RefSim : public periodic_bc,
                 public inflow_bc,
                 public reflecting_bc,
                 public fixed_bc,
-                public double_Mach_ref_bc {
+                public double_Mach_ref_bc,
+                public jet_bc {
   pion_gpu_config cfg;
   SimParams par;
   HarnessGrid *grid;
@@ -478,6 +480,20 @@ struct RefSim : public periodic_bc,
       grid->BC_bd.push_back(b);
     }
   }
+  // jet simulation: JP (sim_params.h:331-341) + the internal JETBC boundary, which the reference puts
+  // after the external ones in the list (uniform_grid.cpp BC_setBCtypes, "internal" boundaries)
+  void set_jet(int radius, const double *state)
+  {
+    JP.jetic = 1;
+    JP.jetradius = radius;
+    for (int v = 0; v < MAX_NVAR; v++) JP.jetstate[v] = (v < cfg.nvar) ? state[v] : 0.0;
+    boundary_data *b = new boundary_data;
+    b->dir = NO;
+    b->ondir = NO;
+    b->itype = JETBC;
+    b->refval = 0;
+    grid->BC_bd.push_back(b);
+  }
   // assign_update_bcs::assign_boundary_data (boundaries/assign_update_bcs.cpp:58-131)
   void assign_bcs()
   {
@@ -495,6 +511,11 @@ struct RefSim : public periodic_bc,
           if (b->refval) b->refval = mem.myfree(b->refval);
           b->data.clear();
           BC_assign_DMACH2(par, grid, b);
+          break;
+        case JETBC:
+          if (b->refval) b->refval = mem.myfree(b->refval);
+          b->data.clear();
+          BC_assign_JETBC(par, grid, b);
           break;
         default: break;
       }
@@ -514,6 +535,7 @@ struct RefSim : public periodic_bc,
         case FIXED: BC_update_FIXED(par, grid, b, cstep, maxstep); break;
         case DMACH: BC_update_DMACH(par, grid, simtime, b, cstep, maxstep); break;
         case DMACH2: BC_update_DMACH2(par, grid, b, cstep, maxstep); break;
+        case JETBC: BC_update_JETBC(par, grid, b, cstep, maxstep); break;
         default: break;
       }
     }
@@ -702,6 +724,11 @@ int ref_update_bcs(void *h, double simtime, int cstep, int maxstep, int assign)
   s->par.simtime = simtime;
   if (assign) s->assign_bcs();
   s->update_bcs(simtime, cstep, maxstep);
+  return 0;
+}
+int ref_set_jet(void *h, int radius, const double *state)
+{
+  ((RefSim *)h)->set_jet(radius, state);
   return 0;
 }
 int ref_calc_dt(void *h, double *t_dyn, double *t_mp)

@@ -241,6 +241,9 @@ struct Handle {
   double refval[6][PION_MAX_NVAR];
   int dmr2_cols = 0;
   long nwind = 0;
+  long njet = 0;          // jet inflow cells (XN ghosts), one state for all
+  long *djet_idx = nullptr;
+  double *djet_state = nullptr;
   long *dwind_idx = nullptr;
   double *dwind_state = nullptr;
   // cooling
@@ -528,6 +531,8 @@ void pion_gpu_destroy(void *handle)
   hipFree(h->ddt_init);
   hipFree(h->dwind_idx);
   hipFree(h->dwind_state);
+  hipFree(h->djet_idx);
+  hipFree(h->djet_state);
   hipFree(h->dcoolT);
   hipFree(h->dcooltab);
   hipFree(h->dcoolslope);
@@ -633,6 +638,42 @@ int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double 
       h->hflags[idx[k]] &= ~PION_CELL_ISDOMAIN;
     }
     HCHECK(h, hipMemcpy(h->dflags, h->hflags.data(), h->g.ncell, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
+{
+  Handle *h = (Handle *)handle;
+  const pion_gpu_config &cfg = h->cfg;
+  const GridDesc &g = h->g;
+  if (cfg.ndim != 3 || cfg.eqntype != PION_EQEUL || !jetstate) {
+    h->err = "jet boundary: 3-D Euler only (jet_boundaries.cpp:88-91,203-206)";
+    return PION_GPU_EINVAL;
+  }
+  // BC_assign_JETBC, 3-D Cartesian (jet_boundaries.cpp:170-201)
+  std::vector<long> idx;
+  const double jr = jetradius * g.dx;
+  for (int iz = 0; iz < g.ng[2]; iz++)
+    for (int iy = 0; iy < g.ng[1]; iy++) {
+      const double y = g.xmin[1] + (2 * iy + 1) * (0.5 * g.dx), z = g.xmin[2] + (2 * iz + 1) * (0.5 * g.dx);
+      if (sqrt(y * y + z * z) <= jr)
+        for (int k = 1; k <= g.nbc[0]; k++) idx.push_back(cell_id(g, -k, iy, iz));
+    }
+  hipFree(h->djet_idx);
+  hipFree(h->djet_state);
+  h->djet_idx = nullptr;
+  h->djet_state = nullptr;
+  h->njet = (long)idx.size();
+  // k_wind takes one state per cell
+  std::vector<double> st((size_t)h->njet * cfg.nvar);
+  for (long k = 0; k < h->njet; k++)
+    for (int v = 0; v < cfg.nvar; v++) st[(size_t)k * cfg.nvar + v] = jetstate[v];
+  if (h->njet > 0) {
+    HCHECK(h, hipMalloc(&h->djet_idx, sizeof(long) * h->njet));
+    HCHECK(h, hipMalloc(&h->djet_state, sizeof(double) * st.size()));
+    HCHECK(h, hipMemcpy(h->djet_idx, idx.data(), sizeof(long) * h->njet, hipMemcpyHostToDevice));
+    HCHECK(h, hipMemcpy(h->djet_state, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -756,6 +797,11 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
     a.dmr_a0 = a.dmr_t3 = 0.0;
     const int n = h->dmr2_cols * g.nbc[1];
     hipLaunchKernelGGL(k_bc_dmr2, dim3((n + 255) / 256), dim3(256), 0, h->stream, a, h->dmr2_cols);
+  }
+  // internal JETBC, listed after the external boundaries (jet_boundaries.cpp:212-262)
+  if (h->njet > 0) {
+    hipLaunchKernelGGL(k_wind, dim3((unsigned)((h->njet + 255) / 256)), dim3(256), 0, h->stream, T, h->djet_idx,
+                       h->djet_state, h->njet, cfg.nvar, g.ncell);
   }
   time_end(h, 2);
   HCHECK(h, hipGetLastError());

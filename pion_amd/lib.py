@@ -46,6 +46,7 @@ def load_library():
     lib.pion_gpu_device_ptr.restype = C.c_void_p
     lib.pion_gpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.pion_gpu_set_comm_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pion_gpu_set_jet.argtypes = [C.c_void_p, C.c_int, _dp]
     lib.pion_gpu_stage_part.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int]
     lib.pion_gpu_synchronize.argtypes = [C.c_void_p]
     lib.pion_gpu_set_wind_cells.argtypes = [C.c_void_p, C.c_long, C.POINTER(C.c_long), _dp]
@@ -77,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "pion_gpu_set_glm_speeds", "pion_gpu_stage", "pion_gpu_advance_time", "pion_gpu_halo_count",
     "pion_gpu_pack_halo", "pion_gpu_unpack_halo", "pion_gpu_interface_flux",
     "pion_gpu_cooling_update", "pion_gpu_cooling_edot", "pion_gpu_enable_timing",
-    "pion_gpu_get_timing", "pion_gpu_stage_part", "pion_gpu_set_comm_stream",
+    "pion_gpu_get_timing", "pion_gpu_stage_part", "pion_gpu_set_comm_stream", "pion_gpu_set_jet",
 ]
 
 
@@ -160,6 +161,10 @@ class GpuSim:
         states = np.ascontiguousarray(states, dtype=np.float64)
         self._chk(self.lib.pion_gpu_set_wind_cells(self.h, idx.size, idx.ctypes.data_as(C.POINTER(C.c_long)),
                                                    _p(states)), "set_wind_cells")
+
+    def set_jet(self, jetradius, jetstate):
+        st = np.ascontiguousarray(jetstate, dtype=np.float64)
+        self._chk(self.lib.pion_gpu_set_jet(self.h, int(jetradius), _p(st)), "set_jet")
 
     def set_cooling_tables(self, T, tabs, slopes):
         T = np.ascontiguousarray(T, dtype=np.float64)

@@ -116,6 +116,22 @@ def hd_blast_octant(n, ndim=3, solver=abi.FLUX_RSroe, ntracer=0, artvisc=abi.AV_
     return cfg, P
 
 
+def jet3d(n, solver=abi.FLUX_RSroe, jetradius=3, strict_fp=0):
+    """3-D Cartesian hydro jet (ics/jet.cpp + boundaries/jet_boundaries.cpp): a uniform ambient medium,
+    outflow on every face, and the internal JETBC on the XN face: a light transonic beam of `jetradius`
+    cells centred on the x axis, carrying tracer 1.  Returns (cfg, P, (jetradius, jetstate)); the
+    backend gets sim.set_jet(jetradius, jetstate) before init."""
+    cfg = abi.make_config(3, [n, n, n], abi.EQEUL, solver, ntracer=1, artvisc=abi.AV_FKJ98_1D, etav=0.15,
+                          gamma=5.0 / 3.0, cfl=0.3, xmin=(0.0, -0.5, -0.5), xmax=(1.0, 0.5, 0.5),
+                          bcs=["outflow"] * 6, refvec=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0], strict_fp=strict_fp)
+    P = alloc(cfg)
+    P[abi.RO] = 1.0
+    P[abi.PG] = 1.0
+    jetstate = np.array([0.5, 1.0, 2.0, 0.0, 0.0, 1.0])   # mildly supersonic: stable from step one
+    # (faster jets need the first-step limit of calc_timestep.cpp:313-323, SimControl.first_step_dt_limit)
+    return cfg, P, (jetradius, jetstate)
+
+
 def double_mach_reflection(nx, solver=abi.FLUX_RSroe, strict_fp=0):
     """test_problems/double_Mach_reflection/params_DMR_n130.txt scaled to nx cells in x
     (aspect 3.25:1): IC_basic_tests::setup_DoubleMachRef (ics/basic_tests.cpp:736)."""

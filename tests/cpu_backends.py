@@ -147,6 +147,10 @@ class CpuSim:
                                             idx.ctypes.data_as(C.POINTER(C.c_long)), _p(states)),
                   "set_wind_cells")
 
+    def set_jet(self, jetradius, jetstate):
+        st = np.ascontiguousarray(jetstate, dtype=np.float64)
+        self._chk(self._f("set_jet")(self.h, C.c_int(int(jetradius)), _p(st)), "set_jet")
+
     def set_cooling_tables(self, T, tabs, slopes):
         T = np.ascontiguousarray(T, dtype=np.float64)
         tabs = np.ascontiguousarray(tabs, dtype=np.float64)

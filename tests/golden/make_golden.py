@@ -14,7 +14,7 @@ Fixtures are data: seeded inputs and the reference's outputs, stored as compress
   flux_kat_b.npz    the same for the Roe-MHD solver (with and without the H-correction eta) and the
                     FKJ98 linear MHD solver, ideal and GLM-MHD (own seed; `make_golden.py b`).
   steps_b.npz       whole-grid dumps for ideal-MHD Roe + H-correction 2-D, GLM-MHD Roe 3-D, GLM-MHD
-                    linear solver 2-D with mixed boundaries.
+                    linear solver 2-D with mixed boundaries, 3-D hydro jet (internal JETBC boundary).
   cell_kat.npz      CellAdvanceTime and CellTimeStep vectors (incl. negative-pressure repair,
                     with and without a microphysics object).
   steps.npz         whole-grid dumps after 2 second-order steps (and per-stage aux data) for small
@@ -62,6 +62,7 @@ def step_dumps(cases, fname):
     for name in cases:
         cfg, P = gc.step_case(name)
         with CpuSim(cfg, "ref") as r:
+            gc.step_setup(name, r)
             sc = driver.SimControl(r, cfg)
             sc.init(P)
             out[name + "_bc"] = r.download(0).astype(np.float64)

@@ -79,10 +79,20 @@ STEP_CASES = ["hd_roe_3d", "hd_fvs_2d_tr", "hd_roe_hcorr_2d", "hd_hll_1d", "mhd_
               "glm_mixed_2d", "dmr_2d", "hd_lf_oa1_3d"]
 
 
-STEP_CASES_B = ["mhd_roe_hcorr_2d", "glm_roe_3d", "glm_linear_2d"]   # steps_b.npz (added with flux_kat_b.npz)
+STEP_CASES_B = ["mhd_roe_hcorr_2d", "glm_roe_3d", "glm_linear_2d", "hd_jet_3d"]   # steps_b.npz (added with flux_kat_b.npz)
+
+
+def step_setup(name, sim):
+    """backend calls a case needs before init (besides the configuration)"""
+    if name == "hd_jet_3d":
+        _, _, (radius, state) = problems.jet3d(12)
+        sim.set_jet(radius, state)
 
 
 def step_case(name, strict_fp=1):
+    if name == "hd_jet_3d":
+        cfg, P, _ = problems.jet3d(12, strict_fp=strict_fp)
+        return cfg, P
     if name == "mhd_roe_hcorr_2d":
         cfg, P = problems.mhd_blastwave(24, 2, abi.EQMHD, abi.FLUX_RSroe, strict_fp=strict_fp)
         cfg.artvisc = abi.AV_HCORR_FKJ98

@@ -61,6 +61,7 @@ def test_flux_kat_gpu(flux_kat, case):
 def test_whole_steps_gpu(steps, name):
     cfg, P = gc.step_case(name)
     with _gpu(cfg) as g:
+        gc.step_setup(name, g)
         sc = driver.SimControl(g, cfg)
         sc.init(P)
         assert np.array_equal(g.download(0), steps[name + "_bc"]), "boundary assignment"

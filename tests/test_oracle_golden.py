@@ -64,6 +64,7 @@ def test_cell_kat(cell_kat, case):
 def test_whole_steps(steps, name):
     cfg, P = gc.step_case(name)
     with CpuSim(cfg, "orc") as o:
+        gc.step_setup(name, o)
         sc = driver.SimControl(o, cfg)
         sc.init(P)
         assert np.array_equal(o.download(0), steps[name + "_bc"]), "boundary assignment"
