@@ -130,3 +130,25 @@ def test_slab_config_and_slices():
     d0, d1 = slab.slab_config(cfg2, 0, 2), slab.slab_config(cfg2, 1, 2)
     assert d0.bc_type[4] == abi.BC_REFLECTING and d0.bc_type[5] == abi.BC_SLAB
     assert d1.bc_type[4] == abi.BC_SLAB and d1.bc_type[5] == abi.BC_OUTFLOW
+
+
+def test_snapshot_restart_is_bit_identical(tmp_path):
+    """write after 2 steps, read back, continue 2 steps == 4 steps in one go (oracle backend)"""
+    from pion_amd import snapshot
+    cfg, P = problems.mhd_blastwave(10, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
+    with CpuSim(cfg, "orc") as o:
+        sc = driver.SimControl(o, cfg)
+        sc.init(P)
+        sc.time_int(2)
+        snapshot.write(str(tmp_path / "s.pionraw"), cfg, o.download(0), sc.simtime, sc.timestep, sc.last_dt)
+        sc.time_int(2)
+        want, twant = o.download(0), sc.simtime
+    cfg2, P2, meta = snapshot.read(str(tmp_path / "s.pionraw"))
+    assert bytes(cfg2) == bytes(cfg)
+    with CpuSim(cfg2, "orc") as o:
+        sc = driver.SimControl(o, cfg2)
+        sc.init(P2, simtime=meta["simtime"])
+        sc.timestep, sc.last_dt = meta["timestep"], meta["last_dt"]
+        sc.time_int(2)
+        assert sc.simtime == twant
+        assert np.array_equal(o.download(0), want)
