@@ -70,6 +70,7 @@ extern "C" {
 #define PION_BC_STWIND 9  /* internal: stellar-wind cells (fixed per-cell state) */
 #define PION_BC_SLAB 10   /* z face owned by a neighbouring GPU (halo exchange) */
 #define PION_BC_JET 11    /* internal: jet inflow cells on the XN face (pion_gpu_set_jet) */
+#define PION_BC_AXISYMMETRIC 12 /* R = 0 axis of a cylindrical (z,R) grid, face YN only (axisymmetric_boundaries.cpp) */
 
 /* cooling functions of mp_only_cooling (microphysics/mp_only_cooling.h) */
 #define PION_COOL_NONE 0
@@ -101,7 +102,8 @@ typedef struct pion_gpu_config {
   int artvisc;   /* SimParams::artviscosity, PION_AV_* */
   int sp_ooa;    /* SimParams::spOOA */
   int tm_ooa;    /* SimParams::tmOOA */
-  int coord_sys; /* 1 = Cartesian (only one supported on the device) */
+  int coord_sys; /* 1 = Cartesian; 2 = cylindrical (z,R), 2-D axisymmetric: x axis = z, y axis = R
+                  * (coord_sys/VectorOps.cpp:662-1245 and the cyl_FV_solver_* classes) */
   int nbc;       /* ghost depth, SimParams::Nbc (2 for second order) */
   int ng[PION_MAX_DIM];      /* on-grid cells per axis (1 on unused axes) */
   double xmin[PION_MAX_DIM]; /* physical position of the low corner of the ON-GRID region */

@@ -41,6 +41,7 @@
 #include "boundaries/fixed_boundaries.h"
 #include "boundaries/double_Mach_ref_boundaries.h"
 #include "boundaries/jet_boundaries.h"
+#include "boundaries/axisymmetric_boundaries.h"
 
 #include "../include/pion_gpu.h"
 
@@ -316,7 +317,8 @@ struct RefSim : public periodic_bc,
                 public reflecting_bc,
                 public fixed_bc,
                 public double_Mach_ref_bc,
-                public jet_bc {
+                public jet_bc,
+                public axisymmetric_bc {
   pion_gpu_config cfg;
   SimParams par;
   HarnessGrid *grid;
@@ -336,6 +338,7 @@ struct RefSim : public periodic_bc,
       case PION_BC_ONEWAY_OUT: return ONEWAY_OUT;
       case PION_BC_DMACH: return DMACH;
       case PION_BC_DMACH2: return DMACH2;
+      case PION_BC_AXISYMMETRIC: return AXISYMMETRIC;
       default: return -1;
     }
   }
@@ -344,7 +347,7 @@ struct RefSim : public periodic_bc,
   {
     par.gridType = 1;
     par.eqntype = c.eqntype;
-    par.coord_sys = COORD_CRT;
+    par.coord_sys = (c.coord_sys == 2) ? COORD_CYL : COORD_CRT;
     par.solverType = c.solver;
     par.eqnNDim = 3;
     par.ndim = c.ndim;
@@ -397,7 +400,16 @@ struct RefSim : public periodic_bc,
     }
     // setup_fixed_grid::set_equations (grid/setup_fixed_grid.cpp:1067-1191), Cartesian
     pion_flt *rv = par.RefVec;
-    if (c.eqntype == EQEUL)
+    if (c.coord_sys == 2) {
+      // cylindrical (z,R) axisymmetry: setup_fixed_grid.cpp:1133-1160
+      if (c.eqntype == EQEUL)
+        solver = new cyl_FV_solver_Hydro_Euler(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);
+      else if (c.eqntype == EQMHD)
+        solver = new cyl_FV_solver_mhd_ideal_adi(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);
+      else
+        solver = new cyl_FV_solver_mhd_mixedGLM_adi(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);
+    }
+    else if (c.eqntype == EQEUL)
       solver = new FV_solver_Hydro_Euler(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);
     else if (c.eqntype == EQMHD)
       solver = new FV_solver_mhd_ideal_adi(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);
@@ -505,6 +517,7 @@ struct RefSim : public periodic_bc,
         case ONEWAY_OUT: BC_assign_ONEWAY_OUT(par, grid, b); break;
         case INFLOW: BC_assign_INFLOW(par, grid, b); break;
         case REFLECTING: BC_assign_REFLECTING(par, grid, b); break;
+        case AXISYMMETRIC: BC_assign_AXISYMMETRIC(par, grid, b); break;
         case FIXED: BC_assign_FIXED(par, grid, b); break;
         case DMACH: BC_assign_DMACH(par, grid, b); break;
         case DMACH2:
@@ -532,6 +545,7 @@ struct RefSim : public periodic_bc,
         case ONEWAY_OUT: BC_update_ONEWAY_OUT(par, grid, b, cstep, maxstep); break;
         case INFLOW: BC_update_INFLOW(par, grid, b, cstep, maxstep); break;
         case REFLECTING: BC_update_REFLECTING(par, grid, b, cstep, maxstep); break;
+        case AXISYMMETRIC: BC_update_AXISYMMETRIC(par, grid, b, cstep, maxstep); break;
         case FIXED: BC_update_FIXED(par, grid, b, cstep, maxstep); break;
         case DMACH: BC_update_DMACH(par, grid, simtime, b, cstep, maxstep); break;
         case DMACH2: BC_update_DMACH2(par, grid, b, cstep, maxstep); break;

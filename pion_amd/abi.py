@@ -18,11 +18,11 @@ FLUX_RSroe_pv, FLUX_FVS, FLUX_RS_HLLD, FLUX_RS_HLL = 5, 6, 7, 8
 AV_NONE, AV_FKJ98_1D, AV_HCORRECTION, AV_HCORR_FKJ98 = 0, 1, 3, 4
 # boundaries
 BC_NONE, BC_PERIODIC, BC_OUTFLOW, BC_INFLOW, BC_REFLECTING, BC_FIXED = 0, 1, 2, 3, 4, 5
-BC_ONEWAY_OUT, BC_DMACH, BC_DMACH2, BC_STWIND, BC_SLAB, BC_JET = 6, 7, 8, 9, 10, 11
+BC_ONEWAY_OUT, BC_DMACH, BC_DMACH2, BC_STWIND, BC_SLAB, BC_JET, BC_AXISYMMETRIC = 6, 7, 8, 9, 10, 11, 12
 BC_NAMES = {
     "periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "inflow": BC_INFLOW,
     "reflecting": BC_REFLECTING, "fixed": BC_FIXED, "one-way-outflow": BC_ONEWAY_OUT,
-    "DMR": BC_DMACH, "slab": BC_SLAB,
+    "DMR": BC_DMACH, "slab": BC_SLAB, "axisymmetric": BC_AXISYMMETRIC,
 }
 COOL_NONE, COOL_WSS09_CIE_LINE_HEAT_COOL = 0, 8
 # cell flags
@@ -55,7 +55,7 @@ class PionGpuConfig(C.Structure):
 def make_config(ndim, ng, eqntype, solver, nvar=None, ntracer=0, artvisc=AV_FKJ98_1D, etav=0.1,
                 gamma=5.0 / 3.0, cfl=0.3, dx=None, xmin=(0.0, 0.0, 0.0), xmax=None, bcs=None,
                 refvec=None, ooa=2, nbc=None, min_temp=0.0, max_temp=1e100, cooling=0,
-                mp_timestep_limit=0, bc_dmach2=0, strict_fp=1):
+                mp_timestep_limit=0, bc_dmach2=0, strict_fp=1, coord_sys=1):
     """Build a PionGpuConfig the way get_sim_info / setup_fixed_grid would
     (source/ics/get_sim_info.cpp:72-180; Nbc = 2 for second order, setup_fixed_grid.cpp:183-190)."""
     cfg = PionGpuConfig()
@@ -67,7 +67,7 @@ def make_config(ndim, ng, eqntype, solver, nvar=None, ntracer=0, artvisc=AV_FKJ9
     cfg.solver = solver
     cfg.artvisc = artvisc
     cfg.sp_ooa = cfg.tm_ooa = ooa
-    cfg.coord_sys = 1
+    cfg.coord_sys = coord_sys   # 1 Cartesian, 2 cylindrical (z,R)
     cfg.nbc = nbc if nbc is not None else (2 if ooa == 2 else 1)
     ng = list(ng) + [1] * (3 - len(ng))
     for a in range(3):

@@ -116,6 +116,37 @@ def hd_blast_octant(n, ndim=3, solver=abi.FLUX_RSroe, ntracer=0, artvisc=abi.AV_
     return cfg, P
 
 
+def blast_axi2d(n, eqntype=abi.EQEUL, solver=abi.FLUX_RSroe, ntracer=0, artvisc=abi.AV_FKJ98_1D, strict_fp=0):
+    """2-D axisymmetric (z,R) blast (test_problems/blastwave_axi2d): n x n/2 cells on z in [-1/2,1/2],
+    R in [0,1/2]; the symmetry axis is the YN face (axisymmetric BC), outflow elsewhere.  MHD: uniform
+    field along z plus a weak toroidal component so that every geometric source term is exercised."""
+    ng = [n, n // 2]
+    nvb = {abi.EQEUL: 5, abi.EQMHD: 8, abi.EQGLM: 9}[eqntype]
+    ref = [1.0, 0.1, 1.0, 1.0, 1.0] + ([1.0, 1.0, 1.0] if nvb >= 8 else []) + ([1.0] if nvb == 9 else []) \
+        + [1.0] * ntracer
+    cfg = abi.make_config(2, ng, eqntype, solver, ntracer=ntracer, artvisc=artvisc, etav=0.1, gamma=5.0 / 3.0,
+                          cfl=0.3, xmin=(-0.5, 0.0, 0.0), xmax=(0.5, 0.5, 0.0),
+                          bcs=["outflow", "outflow", "axisymmetric", "outflow"], refvec=ref, strict_fp=strict_fp,
+                          coord_sys=2)
+    P = alloc(cfg)
+    X, Y, Z = mesh(cfg)
+    r2 = X * X + Y * Y
+    P[abi.RO] = 1.0 + 0.3 * np.exp(-r2 / 0.05)
+    P[abi.PG] = np.where(r2 < 0.15 * 0.15, 10.0, 0.1)
+    P[abi.VX] = 0.2 * np.sin(2 * np.pi * X)
+    P[abi.VY] = 0.1 * Y
+    P[abi.VZ] = 0.3 * Y                      # rotation about the axis (v_theta)
+    if nvb >= 8:
+        P[abi.BX] = 0.5                      # along the axis
+        P[abi.BY] = 0.05 * Y                 # radial, vanishing on the axis
+        P[abi.BZ] = 0.2 * Y                  # toroidal
+    if nvb == 9:
+        P[abi.SI] = 0.01 * np.sin(2 * np.pi * X) * Y
+    for t in range(ntracer):
+        P[nvb + t] = np.where(r2 < 0.15 * 0.15, 1.0, 0.0)
+    return cfg, P
+
+
 def jet3d(n, solver=abi.FLUX_RSroe, jetradius=3, strict_fp=0):
     """3-D Cartesian hydro jet (ics/jet.cpp + boundaries/jet_boundaries.cpp): a uniform ambient medium,
     outflow on every face, and the internal JETBC on the XN face: a light transonic beam of `jetradius`
