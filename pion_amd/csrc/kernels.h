@@ -23,6 +23,7 @@ struct GridDesc {
   long sy, sz;  // strides of y and z in cells
   double dx;
   double xmin[3];
+  int cyl;      // 1: cylindrical (z,R) axisymmetry, axis 1 = R (2-D only)
 };
 
 struct CoolDev {

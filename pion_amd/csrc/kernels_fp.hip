@@ -60,6 +60,14 @@ PDEV double avg_falle(const double a, const double b)
   return (r > 0.0) ? dmin(r, 1.0) * b : 0.0;
 #endif
 }
+// Cylindrical (z,R) grids: centre of a cell along R from its all-cell y index (cell_interface.cpp:506-512)
+// and VectorOps_Cyl::R_com (coord_sys/VectorOps.h:414-418)
+PDEV double cyl_R(const GridDesc &g, const int jy_all)
+{
+  return g.xmin[1] + (2 * (jy_all - g.nbc[1]) + 1) * (0.5 * g.dx);
+}
+PDEV double cyl_Rcom(const double R, const double dR) { return (R + dR * dR / 12. / R); }
+
 // XCD-aware tile decode: workgroups are dealt round-robin to the 8 XCDs (b % 8 share an XCD);
 // give each XCD a contiguous range of tiles so that the halo re-reads of neighbouring tiles hit
 // the same L2.  Placement only changes speed, never results.
@@ -189,6 +197,12 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
 #pragma unroll 1
   for (int ax = 0; ax < a.g.ndim; ax++) {
     const long st = (ax == 0) ? 1 : ((ax == 1) ? a.g.sy : a.g.sz);
+    // R sweep of a cylindrical (z,R) grid: geometry enters slopes, edge states, the flux divergence and
+    // the source terms (VectorOps_Cyl, cyl_FV_solver_*); jy = all-cell y index of this cell
+    const bool cylR = (a.g.cyl != 0 && ax == 1);
+    const int jy = iy + a.g.nbc[1];
+    const double Rm1 = cylR ? cyl_R(a.g, jy - 1) : 0.0, R0 = cylR ? cyl_R(a.g, jy) : 0.0,
+                 Rp1 = cylR ? cyl_R(a.g, jy + 1) : 0.0;
     double qm1[NV], q0[NV], qp1[NV], sm1[NV], s0[NV], sp1[NV];
     {
       double qm2[NV], qp2[NV];
@@ -206,16 +220,34 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
           qm2[s] = qp2[s] = 0.0;
         }
       }
-      // SetSlope (VectorOps.cpp:578-617)
+      // SetSlope (VectorOps.cpp:578-617; along R of a cylindrical grid VectorOps_Cyl::SetSlope
+      // :1103-1204: differences of the cells' centres of mass)
+      if (cylR) {
+        const double c_m2 = cyl_Rcom(cyl_R(a.g, jy - 2), dx), c_m1 = cyl_Rcom(Rm1, dx), c_0 = cyl_Rcom(R0, dx),
+                     c_p1 = cyl_Rcom(Rp1, dx), c_p2 = cyl_Rcom(cyl_R(a.g, jy + 2), dx);
 #pragma unroll
-      for (int s = 0; s < NV; s++) {
-        if (oa2) {
-          sm1[s] = avg_falle((qm1[s] - qm2[s]) / dx, (q0[s] - qm1[s]) / dx);
-          s0[s] = avg_falle((q0[s] - qm1[s]) / dx, (qp1[s] - q0[s]) / dx);
-          sp1[s] = avg_falle((qp1[s] - q0[s]) / dx, (qp2[s] - qp1[s]) / dx);
+        for (int s = 0; s < NV; s++) {
+          if (oa2) {
+            sm1[s] = avg_falle((qm1[s] - qm2[s]) / (c_m1 - c_m2), (q0[s] - qm1[s]) / (c_0 - c_m1));
+            s0[s] = avg_falle((q0[s] - qm1[s]) / (c_0 - c_m1), (qp1[s] - q0[s]) / (c_p1 - c_0));
+            sp1[s] = avg_falle((qp1[s] - q0[s]) / (c_p1 - c_0), (qp2[s] - qp1[s]) / (c_p2 - c_p1));
+          }
+          else {
+            sm1[s] = s0[s] = sp1[s] = 0.0;
+          }
         }
-        else {
-          sm1[s] = s0[s] = sp1[s] = 0.0;
+      }
+      else {
+#pragma unroll
+        for (int s = 0; s < NV; s++) {
+          if (oa2) {
+            sm1[s] = avg_falle((qm1[s] - qm2[s]) / dx, (q0[s] - qm1[s]) / dx);
+            s0[s] = avg_falle((q0[s] - qm1[s]) / dx, (qp1[s] - q0[s]) / dx);
+            sp1[s] = avg_falle((qp1[s] - q0[s]) / dx, (qp2[s] - qp1[s]) / dx);
+          }
+          else {
+            sm1[s] = s0[s] = sp1[s] = 0.0;
+          }
         }
       }
     }
@@ -229,7 +261,13 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
       for (int s = 0; s < NV; s++) {
         const double ql = face ? q0[s] : qm1[s], sl = face ? s0[s] : sm1[s];
         const double qr = face ? qp1[s] : q0[s], sr = face ? sp1[s] : s0[s];
-        if (oa2) {
+        if (oa2 && cylR) {
+          // VectorOps_Cyl::SetEdgeState (VectorOps.cpp:1052-1092): distance of the face from the centre of mass
+          const double Rl = face ? R0 : Rm1, Rr = face ? Rp1 : R0;
+          eL[s] = ql + sl * (Rl + dx * 0.5 - cyl_Rcom(Rl, dx));
+          eR[s] = qr + sr * (Rr - dx * 0.5 - cyl_Rcom(Rr, dx));
+        }
+        else if (oa2) {
           eL[s] = ql + sl * dx * 0.5;
           eR[s] = qr - sr * dx * 0.5;
         }
@@ -258,26 +296,56 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
       // of face 0 and the left cell of face 1
       const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
       const double bm0 = 0.5 * (qm1[qBN] + q0[qBN]);
-      d[uMN] += dt * bm0 * (q0[qBN]) / dx;
-      d[uMT1] += dt * bm0 * (q0[qBT1]) / dx;
-      d[uMT2] += dt * bm0 * (q0[qBT2]) / dx;
-      d[uERG] += dt * bm0 * (uB) / dx;
-      d[uBN] += dt * bm0 * (q0[qVN]) / dx;
-      d[uBT1] += dt * bm0 * (q0[qVT1]) / dx;
-      d[uBT2] += dt * bm0 * (q0[qVT2]) / dx;
+      if (cylR) {
+        // cyl_FV_solver_mhd_ideal_adi::MHDsource, Rcyl (solver_eqn_mhd_adi.cpp:1081-1092): this cell as
+        // the right cell of its lower face ...
+        double rp = Rm1 + dx * 0.5;
+        const double rn = rp;
+        rp += dx;
+        d[uMN] += dt * bm0 * (q0[qBN]) * 2.0 * rn / (rp * rp - rn * rn);
+        d[uMT1] += dt * bm0 * (q0[qBT1]) * 2.0 * rn / (rp * rp - rn * rn);
+        d[uMT2] += dt * bm0 * (q0[qBT2]) * 2.0 * rn / (rp * rp - rn * rn);
+        d[uERG] += dt * bm0 * (uB) * 2.0 * rn / (rp * rp - rn * rn);
+        d[uBN] += dt * bm0 * (q0[qVN]) * 2.0 * rn / (rp * rp - rn * rn);
+        d[uBT1] += dt * bm0 * (q0[qVT1]) * 2.0 * rn / (rp * rp - rn * rn);
+        d[uBT2] += dt * bm0 * (q0[qVT2]) * 2.0 * rn / (rp * rp - rn * rn);
+      }
+      else {
+        d[uMN] += dt * bm0 * (q0[qBN]) / dx;
+        d[uMT1] += dt * bm0 * (q0[qBT1]) / dx;
+        d[uMT2] += dt * bm0 * (q0[qBT2]) / dx;
+        d[uERG] += dt * bm0 * (uB) / dx;
+        d[uBN] += dt * bm0 * (q0[qVN]) / dx;
+        d[uBT1] += dt * bm0 * (q0[qVT1]) / dx;
+        d[uBT2] += dt * bm0 * (q0[qVT2]) / dx;
+      }
       if constexpr (EQ == EQGLM) {
         const double sm0 = 0.5 * (qm1[qSI] + q0[qSI]);
         d[uERG] += dt * sm0 * (q0[qVN] * q0[qSI]) / dx;
         d[uPSI] += dt * sm0 * q0[qVN] / dx;
       }
       const double bm1 = 0.5 * (q0[qBN] + qp1[qBN]);
-      d[uMN] -= dt * bm1 * (q0[qBN]) / dx;
-      d[uMT1] -= dt * bm1 * (q0[qBT1]) / dx;
-      d[uMT2] -= dt * bm1 * (q0[qBT2]) / dx;
-      d[uERG] -= dt * bm1 * (uB) / dx;
-      d[uBN] -= dt * bm1 * (q0[qVN]) / dx;
-      d[uBT1] -= dt * bm1 * (q0[qVT1]) / dx;
-      d[uBT2] -= dt * bm1 * (q0[qVT2]) / dx;
+      if (cylR) {
+        // ... and as the left cell of its upper face
+        const double rp = R0 + dx * 0.5;
+        const double rn = rp - dx;
+        d[uMN] -= dt * bm1 * (q0[qBN]) * 2.0 * rp / (rp * rp - rn * rn);
+        d[uMT1] -= dt * bm1 * (q0[qBT1]) * 2.0 * rp / (rp * rp - rn * rn);
+        d[uMT2] -= dt * bm1 * (q0[qBT2]) * 2.0 * rp / (rp * rp - rn * rn);
+        d[uERG] -= dt * bm1 * (uB) * 2.0 * rp / (rp * rp - rn * rn);
+        d[uBN] -= dt * bm1 * (q0[qVN]) * 2.0 * rp / (rp * rp - rn * rn);
+        d[uBT1] -= dt * bm1 * (q0[qVT1]) * 2.0 * rp / (rp * rp - rn * rn);
+        d[uBT2] -= dt * bm1 * (q0[qVT2]) * 2.0 * rp / (rp * rp - rn * rn);
+      }
+      else {
+        d[uMN] -= dt * bm1 * (q0[qBN]) / dx;
+        d[uMT1] -= dt * bm1 * (q0[qBT1]) / dx;
+        d[uMT2] -= dt * bm1 * (q0[qBT2]) / dx;
+        d[uERG] -= dt * bm1 * (uB) / dx;
+        d[uBN] -= dt * bm1 * (q0[qVN]) / dx;
+        d[uBT1] -= dt * bm1 * (q0[qVT1]) / dx;
+        d[uBT2] -= dt * bm1 * (q0[qVT2]) / dx;
+      }
       if constexpr (EQ == EQGLM) {
         const double sm1g = 0.5 * (q0[qSI] + qp1[qSI]);
         d[uERG] -= dt * sm1g * (q0[qVN] * q0[qSI]) / dx;
@@ -285,10 +353,41 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
       }
     }
     // dU_Cell + DivStateVectorComponent (VectorOps.cpp:624-644)
+    if (cylR) {
+      // VectorOps_Cyl::DivStateVectorComponent, Rcyl (VectorOps.cpp:1211-1245) + geometric_source of the
+      // cyl_FV_solver_* classes (solver_eqn_hydro_adi.cpp:560-590, solver_eqn_mhd_adi.cpp:1001-1030, 1175-1210)
+      double u1[NV];
+      const double rp = R0 + dx * 0.5;
+      const double rn = rp - dx;
 #pragma unroll
-    for (int s = 0; s < NV; s++) {
-      const double u1 = (Fm[s] - Fp[s]) / dx;
-      d[s] += dt * u1;
+      for (int s = 0; s < NV; s++) u1[s] = 2.0 * (rn * Fm[s] - rp * Fp[s]) / (rp * rp - rn * rn);
+      const double Rc = cyl_Rcom(R0, dx);
+      if constexpr (!MHD) {
+        if (oa2) u1[uMN] += (q0[qPG] + (R0 - Rc) * s0[qPG]) / R0;
+        else u1[uMN] += q0[qPG] / R0;
+      }
+      else {
+        const double pm = (q0[qBN] * q0[qBN] + q0[qBT1] * q0[qBT1] + q0[qBT2] * q0[qBT2]) / 2.;
+        if (oa2) {
+          u1[uMN] += (q0[qPG] + pm +
+                      (R0 - Rc) * (s0[qPG] + q0[qBN] * s0[qBN] + q0[qBT1] * s0[qBT1] + q0[qBT2] * s0[qBT2])) /
+                     R0;
+          if constexpr (EQ == EQGLM) u1[uBN] += a.fc.chyp * (q0[qSI] + (R0 - Rc) * s0[qSI]) / R0;
+        }
+        else {
+          u1[uMN] += (q0[qPG] + pm) / R0;
+          if constexpr (EQ == EQGLM) u1[uBN] += a.fc.chyp * q0[qSI] / R0;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NV; s++) d[s] += dt * u1[s];
+    }
+    else {
+#pragma unroll
+      for (int s = 0; s < NV; s++) {
+        const double u1 = (Fm[s] - Fp[s]) / dx;
+        d[s] += dt * u1;
+      }
     }
     from_sweep<NV, MHD>(ax, d, dU);
   }
@@ -474,7 +573,13 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
     const long n = (i[v] > 0) ? c - st : c;
     const long p = (i[v] < a.g.nga[v] - 1) ? c + st : c;
     const double ddx = (n == c || p == c) ? dx : 2.0 * dx;
-    divv += (a.S[(2 + v) * nc + p] - a.S[(2 + v) * nc + n]) / ddx;
+    if (a.g.cyl && v == 1) {
+      // VectorOps_Cyl::Divergence (VectorOps.cpp:891-972): d(R V_R)/(R dR) between the neighbours' centres of mass
+      const double rn = cyl_Rcom(cyl_R(a.g, (n == c) ? i[1] : i[1] - 1), dx);
+      const double rp = cyl_Rcom(cyl_R(a.g, (p == c) ? i[1] : i[1] + 1), dx);
+      divv += 2.0 * (rp * a.S[(2 + v) * nc + p] - rn * a.S[(2 + v) * nc + n]) / (rp * rp - rn * rn);
+    }
+    else divv += (a.S[(2 + v) * nc + p] - a.S[(2 + v) * nc + n]) / ddx;
     // GradZone (VectorOps.cpp:322-368) on the pressure
     const double pp = a.S[1 * nc + p], pn = a.S[1 * nc + n];
     gradp += fabs(pp - pn) / fmin(pp, pn);
@@ -516,7 +621,16 @@ __global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
         const double *b = a.S + (long)(mhd ? rotvar<true>(ax, s) : rotvar<false>(ax, s)) * nc + c;
         const double q0 = b[0], q1 = b[st];
         double s0 = 0.0, s1 = 0.0;
-        if (oa2) {
+        if (oa2 && a.g.cyl && ax == 1) {
+          // VectorOps_Cyl::SetSlope / SetEdgeState along R (VectorOps.cpp:1052-1204); k = all-cell R index
+          const double R0 = cyl_R(a.g, k), R1 = cyl_R(a.g, k + 1);
+          const double c0 = cyl_Rcom(R0, dx), c1 = cyl_Rcom(R1, dx);
+          if (k > 0) s0 = avg_falle((q0 - b[-st]) / (c0 - cyl_Rcom(cyl_R(a.g, k - 1), dx)), (q1 - q0) / (c1 - c0));
+          if (k + 1 < n - 1) s1 = avg_falle((q1 - q0) / (c1 - c0), (b[2 * st] - q1) / (cyl_Rcom(cyl_R(a.g, k + 2), dx) - c1));
+          eL[s] = q0 + s0 * (R0 + dx * 0.5 - c0);
+          eR[s] = q1 + s1 * (R1 - dx * 0.5 - c1);
+        }
+        else if (oa2) {
           if (k > 0) s0 = avg_falle((q0 - b[-st]) / dx, (q1 - q0) / dx);   // first cell: zero slope
           if (k + 1 < n - 1) s1 = avg_falle((q1 - q0) / dx, (b[2 * st] - q1) / dx);  // last cell: zero slope
           eL[s] = q0 + s0 * dx * 0.5;

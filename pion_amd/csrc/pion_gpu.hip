@@ -124,15 +124,25 @@ __global__ __launch_bounds__(256) void k_bc_face(const BCArgs a)
     }
     case PION_BC_OUTFLOW:
     case PION_BC_ONEWAY_OUT:
+    case PION_BC_AXISYMMETRIC:
     case PION_BC_REFLECTING: {
       // all ghost layers copy the FIRST on-grid cell of the row (outflow_boundaries.cpp:50-59)
       const long s = pos ? c - st * depth : c + st * depth;
-      if (a.type == PION_BC_REFLECTING) {
-        // reflecting_boundaries.cpp:34-73,131-153: normal velocity (and normal B) flip sign
+      if (a.type == PION_BC_REFLECTING || a.type == PION_BC_AXISYMMETRIC) {
+        // reflecting_boundaries.cpp:34-73,131-153: normal velocity (and normal B) flip sign;
+        // axisymmetric_boundaries.cpp:34-52,98-137 (R = 0 axis): the radial and the theta components do
+        const bool mhd = (a.eqntype == EQMHD || a.eqntype == EQGLM);
+        const bool axi = (a.type == PION_BC_AXISYMMETRIC);
         for (int v = 0; v < a.nvar; v++) {
           double r = 1.0;
-          if (v == 2 + ax) r = -1.0;
-          if ((a.eqntype == EQMHD || a.eqntype == EQGLM) && v == 5 + ax) r = -1.0;
+          if (axi) {
+            if (v == 3 || v == 4) r = -1.0;
+            if (mhd && (v == 6 || v == 7)) r = -1.0;
+          }
+          else {
+            if (v == 2 + ax) r = -1.0;
+            if (mhd && v == 5 + ax) r = -1.0;
+          }
           T[v * nc + c] = T[v * nc + s] * r;
         }
       }
@@ -348,7 +358,11 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
 {
   if (!cfg || !handle) return PION_GPU_EINVAL;
   if (cfg->ndim < 1 || cfg->ndim > 3 || cfg->nvar > PION_MAX_NVAR) return PION_GPU_EINVAL;
-  if (cfg->coord_sys != 1) return PION_GPU_EINVAL;  // Cartesian only on the device
+  // Cartesian, or cylindrical (z,R) axisymmetry in 2-D (the only cylindrical case the reference's solver
+  // classes accept: solver_eqn_hydro_adi.cpp:540-545, solver_eqn_mhd_adi.cpp:985-990)
+  if (!(cfg->coord_sys == 1 || (cfg->coord_sys == 2 && cfg->ndim == 2))) return PION_GPU_EINVAL;
+  for (int d = 0; d < 2 * cfg->ndim; d++)
+    if (cfg->bc_type[d] == PION_BC_AXISYMMETRIC && !(cfg->coord_sys == 2 && d == 2)) return PION_GPU_EINVAL;
   const int base = (cfg->eqntype == PION_EQEUL) ? 5 : (cfg->eqntype == PION_EQMHD ? 8 : (cfg->eqntype == PION_EQGLM ? 9 : -1));
   if (base < 0 || cfg->nvar != base + cfg->ntracer || cfg->ntracer > PION_MAX_NTR) return PION_GPU_EINVAL;
   if (cfg->sp_ooa == 2 && cfg->nbc < 2) return PION_GPU_EINVAL;
@@ -387,6 +401,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   g.sy = g.nga[0];
   g.sz = (long)g.nga[0] * g.nga[1];
   g.dx = cfg->dx;
+  g.cyl = (cfg->coord_sys == 2) ? 1 : 0;
   *handle = h;
 
   const size_t nb = sizeof(double) * (size_t)cfg->nvar * g.ncell;

@@ -14,7 +14,9 @@ Fixtures are data: seeded inputs and the reference's outputs, stored as compress
   flux_kat_b.npz    the same for the Roe-MHD solver (with and without the H-correction eta) and the
                     FKJ98 linear MHD solver, ideal and GLM-MHD (own seed; `make_golden.py b`).
   steps_b.npz       whole-grid dumps for ideal-MHD Roe + H-correction 2-D, GLM-MHD Roe 3-D, GLM-MHD
-                    linear solver 2-D with mixed boundaries, 3-D hydro jet (internal JETBC boundary).
+                    linear solver 2-D with mixed boundaries, 3-D hydro jet (internal JETBC boundary), and five
+                    2-D cylindrical (z,R) axisymmetric blasts (HD Roe, HD H-correction + tracer, ideal-MHD
+                    HLLD, GLM-MHD HLLD + tracer, GLM-MHD Roe first order).
   cell_kat.npz      CellAdvanceTime and CellTimeStep vectors (incl. negative-pressure repair,
                     with and without a microphysics object).
   steps.npz         whole-grid dumps after 2 second-order steps (and per-stage aux data) for small
