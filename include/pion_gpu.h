@@ -103,7 +103,8 @@ typedef struct pion_gpu_config {
   int sp_ooa;    /* SimParams::spOOA */
   int tm_ooa;    /* SimParams::tmOOA */
   int coord_sys; /* 1 = Cartesian; 2 = cylindrical (z,R), 2-D axisymmetric: x axis = z, y axis = R
-                  * (coord_sys/VectorOps.cpp:662-1245 and the cyl_FV_solver_* classes) */
+                  * (coord_sys/VectorOps.cpp:662-1245 and the cyl_FV_solver_* classes); 3 = spherical
+                  * symmetry, 1-D, Euler only (VectorOps_spherical.cpp, sph_FV_solver_Hydro_Euler) */
   int nbc;       /* ghost depth, SimParams::Nbc (2 for second order) */
   int ng[PION_MAX_DIM];      /* on-grid cells per axis (1 on unused axes) */
   double xmin[PION_MAX_DIM]; /* physical position of the low corner of the ON-GRID region */

@@ -347,7 +347,7 @@ struct RefSim : public periodic_bc,
   {
     par.gridType = 1;
     par.eqntype = c.eqntype;
-    par.coord_sys = (c.coord_sys == 2) ? COORD_CYL : COORD_CRT;
+    par.coord_sys = (c.coord_sys == 2) ? COORD_CYL : ((c.coord_sys == 3) ? COORD_SPH : COORD_CRT);
     par.solverType = c.solver;
     par.eqnNDim = 3;
     par.ndim = c.ndim;
@@ -400,7 +400,11 @@ struct RefSim : public periodic_bc,
     }
     // setup_fixed_grid::set_equations (grid/setup_fixed_grid.cpp:1067-1191), Cartesian
     pion_flt *rv = par.RefVec;
-    if (c.coord_sys == 2) {
+    if (c.coord_sys == 3) {
+      // spherical symmetry, 1-D, hydro only (setup_fixed_grid.cpp:1161-1175)
+      solver = new sph_FV_solver_Hydro_Euler(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);
+    }
+    else if (c.coord_sys == 2) {
       // cylindrical (z,R) axisymmetry: setup_fixed_grid.cpp:1133-1160
       if (c.eqntype == EQEUL)
         solver = new cyl_FV_solver_Hydro_Euler(c.nvar, c.ndim, c.cfl, c.gamma, rv, c.etav, c.ntracer);

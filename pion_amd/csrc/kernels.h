@@ -23,7 +23,8 @@ struct GridDesc {
   long sy, sz;  // strides of y and z in cells
   double dx;
   double xmin[3];
-  int cyl;      // 1: cylindrical (z,R) axisymmetry, axis 1 = R (2-D only)
+  int cyl;      // 1: cylindrical (z,R) axisymmetry, axis 1 = R (2-D only); 2: spherical symmetry, axis 0 = R (1-D)
+  const double *sph_vol;  // spherical: (rp^3 - rn^3)/3 per all-cell x index, evaluated on the host (libm pow)
 };
 
 struct CoolDev {

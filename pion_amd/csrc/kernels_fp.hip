@@ -67,6 +67,19 @@ PDEV double cyl_R(const GridDesc &g, const int jy_all)
   return g.xmin[1] + (2 * (jy_all - g.nbc[1]) + 1) * (0.5 * g.dx);
 }
 PDEV double cyl_Rcom(const double R, const double dR) { return (R + dR * dR / 12. / R); }
+// spherical symmetry (1-D): cell centre from the all-cell x index; R3 and R_com of VectorOps_Sph
+// (coord_sys/VectorOps_spherical.h:172-196)
+PDEV double sph_R(const GridDesc &g, const int ix_all)
+{
+  return g.xmin[0] + (2 * (ix_all - g.nbc[0]) + 1) * (0.5 * g.dx);
+}
+PDEV double sph_R3(const double R, const double dR) { return (R + dR * dR / 12.0 / R); }
+PDEV double sph_Rcom(const double R, const double dR)
+{
+  double delta2 = dR / R;
+  delta2 *= delta2;
+  return R * (1.0 + 0.25 * delta2) / (1.0 + delta2 / 12.0);
+}
 
 // XCD-aware tile decode: workgroups are dealt round-robin to the 8 XCDs (b % 8 share an XCD);
 // give each XCD a contiguous range of tiles so that the halo re-reads of neighbouring tiles hit
@@ -199,10 +212,20 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
     const long st = (ax == 0) ? 1 : ((ax == 1) ? a.g.sy : a.g.sz);
     // R sweep of a cylindrical (z,R) grid: geometry enters slopes, edge states, the flux divergence and
     // the source terms (VectorOps_Cyl, cyl_FV_solver_*); jy = all-cell y index of this cell
-    const bool cylR = (a.g.cyl != 0 && ax == 1);
-    const int jy = iy + a.g.nbc[1];
-    const double Rm1 = cylR ? cyl_R(a.g, jy - 1) : 0.0, R0 = cylR ? cyl_R(a.g, jy) : 0.0,
-                 Rp1 = cylR ? cyl_R(a.g, jy + 1) : 0.0;
+    const bool cylR = (a.g.cyl == 1 && ax == 1);
+    const bool sphR = (a.g.cyl == 2 && ax == 0);   // spherical symmetry: the only axis is R
+    const int jy = sphR ? ix + a.g.nbc[0] : iy + a.g.nbc[1];
+    double Rm1 = 0.0, R0 = 0.0, Rp1 = 0.0;
+    if (cylR) {
+      Rm1 = cyl_R(a.g, jy - 1);
+      R0 = cyl_R(a.g, jy);
+      Rp1 = cyl_R(a.g, jy + 1);
+    }
+    else if (sphR) {
+      Rm1 = sph_R(a.g, jy - 1);
+      R0 = sph_R(a.g, jy);
+      Rp1 = sph_R(a.g, jy + 1);
+    }
     double qm1[NV], q0[NV], qp1[NV], sm1[NV], s0[NV], sp1[NV];
     {
       double qm2[NV], qp2[NV];
@@ -222,9 +245,13 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
       }
       // SetSlope (VectorOps.cpp:578-617; along R of a cylindrical grid VectorOps_Cyl::SetSlope
       // :1103-1204: differences of the cells' centres of mass)
-      if (cylR) {
-        const double c_m2 = cyl_Rcom(cyl_R(a.g, jy - 2), dx), c_m1 = cyl_Rcom(Rm1, dx), c_0 = cyl_Rcom(R0, dx),
-                     c_p1 = cyl_Rcom(Rp1, dx), c_p2 = cyl_Rcom(cyl_R(a.g, jy + 2), dx);
+      if (cylR || sphR) {
+        // (VectorOps_Sph::SetSlope, VectorOps_spherical.cpp:358-440, has the same form with its own R_com)
+        const double c_m2 = sphR ? sph_Rcom(sph_R(a.g, jy - 2), dx) : cyl_Rcom(cyl_R(a.g, jy - 2), dx),
+                     c_m1 = sphR ? sph_Rcom(Rm1, dx) : cyl_Rcom(Rm1, dx),
+                     c_0 = sphR ? sph_Rcom(R0, dx) : cyl_Rcom(R0, dx),
+                     c_p1 = sphR ? sph_Rcom(Rp1, dx) : cyl_Rcom(Rp1, dx),
+                     c_p2 = sphR ? sph_Rcom(sph_R(a.g, jy + 2), dx) : cyl_Rcom(cyl_R(a.g, jy + 2), dx);
 #pragma unroll
         for (int s = 0; s < NV; s++) {
           if (oa2) {
@@ -266,6 +293,12 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
           const double Rl = face ? R0 : Rm1, Rr = face ? Rp1 : R0;
           eL[s] = ql + sl * (Rl + dx * 0.5 - cyl_Rcom(Rl, dx));
           eR[s] = qr + sr * (Rr - dx * 0.5 - cyl_Rcom(Rr, dx));
+        }
+        else if (oa2 && sphR) {
+          // VectorOps_Sph::SetEdgeState (VectorOps_spherical.cpp:294-350)
+          const double Rl = face ? R0 : Rm1, Rr = face ? Rp1 : R0;
+          eL[s] = ql + sl * (Rl + 0.5 * dx - sph_Rcom(Rl, dx));
+          eR[s] = qr + sr * (Rr - 0.5 * dx - sph_Rcom(Rr, dx));
         }
         else if (oa2) {
           eL[s] = ql + sl * dx * 0.5;
@@ -353,7 +386,22 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
       }
     }
     // dU_Cell + DivStateVectorComponent (VectorOps.cpp:624-644)
-    if (cylR) {
+    if (sphR) {
+      // VectorOps_Sph::DivStateVectorComponent (VectorOps_spherical.cpp:449-475; the cell's shell volume
+      // (rp^3-rn^3)/3 comes from the host, where pow() is the reference's) and
+      // sph_FV_solver_Hydro_Euler::geometric_source (solver_eqn_hydro_adi.cpp:648-675)
+      double u1[NV];
+      const double rp = R0 + 0.5 * dx;
+      const double rn = rp - dx;
+      const double rc = a.g.sph_vol[jy];
+#pragma unroll
+      for (int s = 0; s < NV; s++) u1[s] = (rn * rn * Fm[s] - rp * rp * Fp[s]) / rc;
+      if (oa2) u1[uMN] += 2.0 * ((q0[qPG] - s0[qPG] * sph_Rcom(R0, dx)) / sph_R3(R0, dx) + s0[qPG]);
+      else u1[uMN] += 2.0 * q0[qPG] / sph_R3(R0, dx);
+#pragma unroll
+      for (int s = 0; s < NV; s++) d[s] += dt * u1[s];
+    }
+    else if (cylR) {
       // VectorOps_Cyl::DivStateVectorComponent, Rcyl (VectorOps.cpp:1211-1245) + geometric_source of the
       // cyl_FV_solver_* classes (solver_eqn_hydro_adi.cpp:560-590, solver_eqn_mhd_adi.cpp:1001-1030, 1175-1210)
       double u1[NV];
@@ -573,7 +621,7 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
     const long n = (i[v] > 0) ? c - st : c;
     const long p = (i[v] < a.g.nga[v] - 1) ? c + st : c;
     const double ddx = (n == c || p == c) ? dx : 2.0 * dx;
-    if (a.g.cyl && v == 1) {
+    if (a.g.cyl == 1 && v == 1) {
       // VectorOps_Cyl::Divergence (VectorOps.cpp:891-972): d(R V_R)/(R dR) between the neighbours' centres of mass
       const double rn = cyl_Rcom(cyl_R(a.g, (n == c) ? i[1] : i[1] - 1), dx);
       const double rp = cyl_Rcom(cyl_R(a.g, (p == c) ? i[1] : i[1] + 1), dx);
@@ -621,7 +669,16 @@ __global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
         const double *b = a.S + (long)(mhd ? rotvar<true>(ax, s) : rotvar<false>(ax, s)) * nc + c;
         const double q0 = b[0], q1 = b[st];
         double s0 = 0.0, s1 = 0.0;
-        if (oa2 && a.g.cyl && ax == 1) {
+        if (oa2 && a.g.cyl == 2) {
+          // VectorOps_Sph::SetSlope / SetEdgeState (VectorOps_spherical.cpp:294-440); k = all-cell R index
+          const double R0 = sph_R(a.g, k), R1 = sph_R(a.g, k + 1);
+          const double c0 = sph_Rcom(R0, dx), c1 = sph_Rcom(R1, dx);
+          if (k > 0) s0 = avg_falle((q0 - b[-st]) / (c0 - sph_Rcom(sph_R(a.g, k - 1), dx)), (q1 - q0) / (c1 - c0));
+          if (k + 1 < n - 1) s1 = avg_falle((q1 - q0) / (c1 - c0), (b[2 * st] - q1) / (sph_Rcom(sph_R(a.g, k + 2), dx) - c1));
+          eL[s] = q0 + s0 * (R0 + 0.5 * dx - c0);
+          eR[s] = q1 + s1 * (R1 - 0.5 * dx - c1);
+        }
+        else if (oa2 && a.g.cyl == 1 && ax == 1) {
           // VectorOps_Cyl::SetSlope / SetEdgeState along R (VectorOps.cpp:1052-1204); k = all-cell R index
           const double R0 = cyl_R(a.g, k), R1 = cyl_R(a.g, k + 1);
           const double c0 = cyl_Rcom(R0, dx), c1 = cyl_Rcom(R1, dx);

@@ -243,6 +243,7 @@ struct Handle {
   bool own_state = true;
   uint8_t *dflags = nullptr, *dhll = nullptr;
   double *deta = nullptr;
+  double *dsphvol = nullptr;   // spherical 1-D: shell volumes/(4 pi) per cell
   int *derr = nullptr;
   unsigned long long *ddt = nullptr;   // [0]=min t_dyn, [1]=min t_mp (bit patterns)
   unsigned long long *ddt_init = nullptr;  // {1e100, 1e99} on the device: reset source (no host buffer in flight)
@@ -360,7 +361,10 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (cfg->ndim < 1 || cfg->ndim > 3 || cfg->nvar > PION_MAX_NVAR) return PION_GPU_EINVAL;
   // Cartesian, or cylindrical (z,R) axisymmetry in 2-D (the only cylindrical case the reference's solver
   // classes accept: solver_eqn_hydro_adi.cpp:540-545, solver_eqn_mhd_adi.cpp:985-990)
-  if (!(cfg->coord_sys == 1 || (cfg->coord_sys == 2 && cfg->ndim == 2))) return PION_GPU_EINVAL;
+  // or spherical symmetry in 1-D, hydro only (sph_FV_solver_Hydro_Euler, solver_eqn_hydro_adi.cpp:620-640)
+  if (!(cfg->coord_sys == 1 || (cfg->coord_sys == 2 && cfg->ndim == 2)
+        || (cfg->coord_sys == 3 && cfg->ndim == 1 && cfg->eqntype == PION_EQEUL)))
+    return PION_GPU_EINVAL;
   for (int d = 0; d < 2 * cfg->ndim; d++)
     if (cfg->bc_type[d] == PION_BC_AXISYMMETRIC && !(cfg->coord_sys == 2 && d == 2)) return PION_GPU_EINVAL;
   const int base = (cfg->eqntype == PION_EQEUL) ? 5 : (cfg->eqntype == PION_EQMHD ? 8 : (cfg->eqntype == PION_EQGLM ? 9 : -1));
@@ -401,7 +405,8 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   g.sy = g.nga[0];
   g.sz = (long)g.nga[0] * g.nga[1];
   g.dx = cfg->dx;
-  g.cyl = (cfg->coord_sys == 2) ? 1 : 0;
+  g.cyl = (cfg->coord_sys == 2) ? 1 : ((cfg->coord_sys == 3) ? 2 : 0);
+  g.sph_vol = nullptr;
   *handle = h;
 
   const size_t nb = sizeof(double) * (size_t)cfg->nvar * g.ncell;
@@ -410,6 +415,19 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   HCHECK(h, hipMemset(h->dP, 0, nb));
   HCHECK(h, hipMemset(h->dPh, 0, nb));
   HCHECK(h, hipMalloc(&h->dflags, g.ncell));
+  if (g.cyl == 2) {
+    // VectorOps_Sph::DivStateVectorComponent: rc = (pow(rp,3.0) - pow(rn,3.0))/3.0 with the host's libm
+    std::vector<double> vol(g.nga[0]);
+    for (int i = 0; i < g.nga[0]; i++) {
+      double rc = g.xmin[0] + (2 * (i - g.nbc[0]) + 1) * (0.5 * g.dx);
+      const double rp = rc + 0.5 * g.dx;
+      const double rn = rp - g.dx;
+      vol[i] = (pow(rp, 3.0) - pow(rn, 3.0)) / 3.0;
+    }
+    HCHECK(h, hipMalloc(&h->dsphvol, sizeof(double) * vol.size()));
+    HCHECK(h, hipMemcpy(h->dsphvol, vol.data(), sizeof(double) * vol.size(), hipMemcpyHostToDevice));
+    g.sph_vol = h->dsphvol;
+  }
   HCHECK(h, hipMalloc(&h->derr, 64));
   HCHECK(h, hipMemset(h->derr, 0, 64));
   HCHECK(h, hipMalloc(&h->ddt, 2 * sizeof(unsigned long long)));
@@ -541,6 +559,7 @@ void pion_gpu_destroy(void *handle)
   hipFree(h->dflags);
   hipFree(h->dhll);
   hipFree(h->deta);
+  hipFree(h->dsphvol);
   hipFree(h->derr);
   hipFree(h->ddt);
   hipFree(h->ddt_init);

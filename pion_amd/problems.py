@@ -147,6 +147,22 @@ def blast_axi2d(n, eqntype=abi.EQEUL, solver=abi.FLUX_RSroe, ntracer=0, artvisc=
     return cfg, P
 
 
+def blast_sph1d(n, solver=abi.FLUX_RSroe, ntracer=0, artvisc=abi.AV_FKJ98_1D, strict_fp=0):
+    """1-D spherically symmetric blast (test_problems/blastwave_sph1d): R in [0,1], reflecting at the
+    origin, outflow outside; hydro only, as in the reference (sph_FV_solver_Hydro_Euler)."""
+    cfg = abi.make_config(1, [n], abi.EQEUL, solver, ntracer=ntracer, artvisc=artvisc, etav=0.1, gamma=5.0 / 3.0,
+                          cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(1.0, 0.0, 0.0), bcs=["reflecting", "outflow"],
+                          refvec=[1.0, 0.1, 1.0, 1.0, 1.0] + [1.0] * ntracer, strict_fp=strict_fp, coord_sys=3)
+    P = alloc(cfg)
+    X, Y, Z = mesh(cfg)
+    P[abi.RO] = 1.0 + 0.5 * np.exp(-(X / 0.3) ** 2)
+    P[abi.PG] = np.where(X < 0.2, 10.0, 0.1)
+    P[abi.VX] = 0.3 * X
+    for t in range(ntracer):
+        P[5 + t] = np.where(X < 0.2, 1.0, 0.0)
+    return cfg, P
+
+
 def jet3d(n, solver=abi.FLUX_RSroe, jetradius=3, strict_fp=0):
     """3-D Cartesian hydro jet (ics/jet.cpp + boundaries/jet_boundaries.cpp): a uniform ambient medium,
     outflow on every face, and the internal JETBC on the XN face: a light transonic beam of `jetradius`

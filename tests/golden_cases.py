@@ -80,7 +80,8 @@ STEP_CASES = ["hd_roe_3d", "hd_fvs_2d_tr", "hd_roe_hcorr_2d", "hd_hll_1d", "mhd_
 
 
 STEP_CASES_B = ["mhd_roe_hcorr_2d", "glm_roe_3d", "glm_linear_2d", "hd_jet_3d",
-                "cyl_hd_roe", "cyl_hd_hcorr_tr", "cyl_mhd_hlld", "cyl_glm_hlld", "cyl_glm_roe_oa1"]   # steps_b.npz (added with flux_kat_b.npz)
+                "cyl_hd_roe", "cyl_hd_hcorr_tr", "cyl_mhd_hlld", "cyl_glm_hlld", "cyl_glm_roe_oa1",
+                "sph_hd_roe_tr", "sph_hd_hcorr", "sph_hd_hybrid_oa1"]   # steps_b.npz (added with flux_kat_b.npz)
 
 
 def step_setup(name, sim):
@@ -93,6 +94,14 @@ def step_setup(name, sim):
 def step_case(name, strict_fp=1):
     if name == "hd_jet_3d":
         cfg, P, _ = problems.jet3d(12, strict_fp=strict_fp)
+        return cfg, P
+    if name == "sph_hd_roe_tr":
+        return problems.blast_sph1d(64, abi.FLUX_RSroe, ntracer=1, strict_fp=strict_fp)
+    if name == "sph_hd_hcorr":
+        return problems.blast_sph1d(64, abi.FLUX_RSroe, artvisc=abi.AV_HCORR_FKJ98, strict_fp=strict_fp)
+    if name == "sph_hd_hybrid_oa1":
+        cfg, P = problems.blast_sph1d(64, abi.FLUX_RShybrid, strict_fp=strict_fp)
+        cfg.sp_ooa = cfg.tm_ooa = 1
         return cfg, P
     if name == "cyl_hd_roe":
         return problems.blast_axi2d(24, abi.EQEUL, abi.FLUX_RSroe, strict_fp=strict_fp)
