@@ -83,14 +83,16 @@ PDEV void apply_axis(double *d, const double *q0, const double bnm, const double
 // CellAdvanceTime + temperature clamp + store (see k_stage)
 template <int EQ, int NTR>
 PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, const double *dU, int &err,
-                           double *Pfout = nullptr)
+                           double *Pfout = nullptr, const bool no_mp = false)
 {
   typedef Eqn<EQ, NTR> E;
   constexpr int NV = E::NV;
   const double g = a.fc.gamma;
   const long nc = a.g.ncell;
   double u1[NV], Pf[NV];
-  if (a.fc.mp.present) {
+  MPd mp = a.fc.mp;
+  if (no_mp) mp.present = false;  // compile-time constant in the PLAIN instances of k_stage_rows
+  if (mp.present) {
     double Pi[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) Pi[v] = P0[v];
@@ -100,12 +102,12 @@ PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, 
   else E::PtoU(P0, u1, g);
 #pragma unroll
   for (int v = 0; v < NV; v++) u1[v] += dU[v];
-  E::UtoP(u1, Pf, a.fc.min_temp, g, a.fc.mp, err);
-  if (a.fc.mp.present) E::apply_sCMA(Pf);
+  E::UtoP(u1, Pf, a.fc.min_temp, g, mp, err);
+  if (mp.present) E::apply_sCMA(Pf);
   if constexpr (EQ == EQGLM) Pf[qSI] *= a.glm_damp;
-  if (a.fc.mp.present) {
-    const double T = Pf[qPG] * a.fc.mp.Mu_tot_over_kB / Pf[qRO];
-    if (T > a.max_temp) Pf[qPG] = Pf[qRO] * a.max_temp / a.fc.mp.Mu_tot_over_kB;
+  if (mp.present) {
+    const double T = Pf[qPG] * mp.Mu_tot_over_kB / Pf[qRO];
+    if (T > a.max_temp) Pf[qPG] = Pf[qRO] * a.max_temp / mp.Mu_tot_over_kB;
   }
 #pragma unroll
   for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v];

@@ -20,7 +20,7 @@
 #ifndef PION_ROWS_ATTR
 #define PION_ROWS_ATTR
 #endif
-template <int EQ, int NTR, int SOLVER, int OAMODE>
+template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN>
 __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageArgs a)
 {
   typedef Eqn<EQ, NTR> E;
@@ -63,7 +63,11 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
   // instance was validated in; specialised instances are only built where they are exercised and
   // tested, see stage_rows_go).
   const bool oa2 = (OAMODE == 0) ? (a.space_ooa == 2) : (OAMODE == 2);
-  const bool hcorr = (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
+  // PLAIN: no H-correction, no cooling / microphysics object -- known at compile time (the common
+  // production case), so their code and registers disappear
+  const bool hcorr = PLAIN ? false : (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
+  FluxCtx fc = a.fc;
+  if (PLAIN) fc.mp.present = 0;
   int err = 0;
   double tdyn = 1.e100, tmp = 1.0e99;  // running minima for the fused time-step reduction
 
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
       }
       load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
 
-      if (!prime && a.cooling != 0) {
+      if (!PLAIN && !prime && a.cooling != 0) {
         if (fl & 4) {
           // calc_noRT_microphysics_dU (time_integrator.cpp:438-489)
           double pn[NV], ui[NV], uf[NV];
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
         bool use_hll = false;
         if constexpr (MHD && SOLVER == FLUX_RS_HLLD) use_hll = (a.hllflag[cl] | a.hllflag[cl + st]) != 0;
-        FX::intercell_flux(eL, eR, f, pstar, a.fc, hc_eta, use_hll, err);
+        FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 
         if (t == 0) {
           double Fm[NV];
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
 #pragma unroll
           for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v] = P0[v];
         }
-        else cell_update_store<EQ, NTR>(a, c, P0, dU, err, Pf);
+        else cell_update_store<EQ, NTR>(a, c, P0, dU, err, Pf, PLAIN);
         if (a.dtres) {
           // calc_dynamics_dt / calc_microphysics_dt (calc_timestep.cpp:271-507) of the state just
           // written: after a full step it is the state the next step's dt is computed from
@@ -395,13 +399,21 @@ static int stage_rows_go(const StageArgs &a0, hipStream_t s)
   // other per-instance miscompiles listed in the Makefile, so the rest keep the run-time form
   constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL);
   if constexpr (specialise) {
-    if (a.space_ooa == 2)
-      hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 2>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+    const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
+                        && a.fc.artvisc != AV_HCORR_FKJ98);
+    if (plain) {
+      if (a.space_ooa == 2)
+        hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 2, true>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+      else
+        hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 1, true>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+    }
+    else if (a.space_ooa == 2)
+      hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 2, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
     else
-      hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 1>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+      hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 1, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
   }
   else
-    hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 0>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+    hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 0, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
   return (int)hipGetLastError();
 }
 

@@ -243,3 +243,18 @@ def test_fused_dt_equals_dt_kernel(case, strict):
                 assert fused == kern, (fused, kern)
             else:
                 assert np.allclose(fused, kern, rtol=1e-13, atol=0.0), (fused, kern)
+
+
+@pytest.mark.parametrize("strict", [1, 0])
+@pytest.mark.parametrize("ntr", [0, 1, 2])
+@pytest.mark.parametrize("eq", [abi.EQMHD, abi.EQGLM])
+def test_hlld_with_hcorrection_instances_3d(eq, ntr, strict, monkeypatch):
+    """the HLLD instances of k_stage_rows exist twice (with and without the H-correction / microphysics
+    code, see stage_rows_go); the blast tests above run the plain ones, this one the others"""
+    cfg0, P0 = problems.mhd_blastwave(14, 3, eq, abi.FLUX_RS_HLLD, strict_fp=strict)
+    cfg0.artvisc = abi.AV_HCORR_FKJ98
+    cfg, P = _with_tracers(cfg0, P0, ntr)
+    if strict:
+        run_pair(cfg, P, 2)
+    else:
+        _fast_rows_vs_cell(cfg, P, 2, monkeypatch)
