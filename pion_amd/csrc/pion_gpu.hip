@@ -991,8 +991,9 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     while (a.zchunk > 8 && per_plane_chunk * ((kz1 - kz0 + a.zchunk - 1) / a.zchunk) < 4096) a.zchunk /= 2;
   }
   // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
-  const bool fuse_dt = h->fuse_dt && is_full_step && a.use_march == 2 && h->g.ndim == 3 && h->g.nbc[2] >= 2
-                       && a.out == h->dP;
+  // (second-order stages only: the first-order instances of k_stage_rows carry no reduction code)
+  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march == 2 && h->g.ndim == 3
+                       && h->g.nbc[2] >= 2 && a.out == h->dP;
   a.dtres = nullptr;
   a.cfl = cfg.cfl;
   a.dt_mp = (cfg.cooling != 0 && cfg.mp_timestep_limit != 0) ? 1 : 0;
