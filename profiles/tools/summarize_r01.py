@@ -53,8 +53,15 @@ def main():
     write_corr = (2.0 * n * 8) / (w12 * KB)
     bf = counter_per_kernel("pmc_fetch", "FETCH_SIZE")
     bw = counter_per_kernel("pmc_write", "WRITE_SIZE")
-    name, (fs, nf) = pick(bf, "k_stage_rows")
-    _, (ws, nw) = pick(bw, "k_stage_rows")
+    def stage_mean(d):
+        """per-launch mean over every k_stage_rows instance (the first- and the second-order stage are
+        separate template instances; a step launches each once)"""
+        tot = sum(v * n for k, (v, n) in d.items() if "k_stage_rows" in k)
+        cnt = sum(n for k, (v, n) in d.items() if "k_stage_rows" in k)
+        names = sorted(k for k in d if "k_stage_rows" in k)
+        return " + ".join(names), tot / cnt, cnt
+    name, fs, nf = stage_mean(bf)
+    _, ws, nw = stage_mean(bw)
     out = {
         "workload": "bench.py --steps 3 --warmup 1 (512^3 GLM-MHD HLLD, fast mode)",
         "kernel": name,
