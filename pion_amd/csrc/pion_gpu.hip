@@ -285,6 +285,15 @@ struct Handle {
     }                                                                              \
   } while (0)
 
+// Every entry point selects the handle's device first: the current device is per-thread state, and
+// distinct handles may be driven from distinct host threads (or interleaved on one thread).
+static inline Handle *use(void *handle)
+{
+  Handle *h = (Handle *)handle;
+  if (h) (void)hipSetDevice(h->device);
+  return h;
+}
+
 // Two-stream mode: everything on the compute stream that touches the z ghost planes must run after
 // the last unpack on the comm stream.  One wait is enough, later work is ordered behind it.
 int order_after_unpack(Handle *h)
@@ -548,7 +557,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
 
 void pion_gpu_destroy(void *handle)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   if (!h) return;
   hipSetDevice(h->device);
   hipDeviceSynchronize();
@@ -579,7 +588,7 @@ void pion_gpu_destroy(void *handle)
 
 int pion_gpu_last_error(void *handle, char *buf, int len)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   if (!h || !buf || len <= 0) return PION_GPU_EINVAL;
   snprintf(buf, len, "%s", h->err.c_str());
   return 0;
@@ -590,7 +599,7 @@ int pion_gpu_ng_all(void *handle, int axis) { return ((Handle *)handle)->g.nga[a
 
 int pion_gpu_upload(void *handle, const double *P_soa)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   const size_t nb = sizeof(double) * (size_t)h->cfg.nvar * h->g.ncell;
   HCHECK(h, hipMemcpyAsync(h->dP, P_soa, nb, hipMemcpyHostToDevice, h->stream));
   HCHECK(h, hipMemcpyAsync(h->dPh, h->dP, nb, hipMemcpyDeviceToDevice, h->stream));
@@ -602,7 +611,7 @@ int pion_gpu_upload(void *handle, const double *P_soa)
 
 int pion_gpu_download(void *handle, int which, double *P_soa)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   const size_t nb = sizeof(double) * (size_t)h->cfg.nvar * h->g.ncell;
   // after a full step the reference has Ph == P everywhere (time_integrator.cpp:938-939)
   const double *src = (which == 1 && h->ph_valid) ? h->dPh : h->dP;
@@ -614,7 +623,7 @@ int pion_gpu_download(void *handle, int which, double *P_soa)
 
 int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   if (!dP || !dPh) return PION_GPU_EINVAL;
   if (h->own_state) {
     hipFree(h->dP);
@@ -629,7 +638,7 @@ int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh)
 }
 void *pion_gpu_device_ptr(void *handle, int which)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   h->dt_cached = false;  // the caller may write through the pointer
   return which == 0 ? (void *)h->dP : (void *)h->dPh;
 }
@@ -640,14 +649,14 @@ int pion_gpu_set_stream(void *handle, void *stream)
 }
 int pion_gpu_set_comm_stream(void *handle, void *stream)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   h->comm_stream = (hipStream_t)stream;
   h->ev_unpacked_valid = false;
   return 0;
 }
 int pion_gpu_synchronize(void *handle)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   HCHECK(h, hipStreamSynchronize(h->stream));
   if (h->comm_stream && h->comm_stream != h->stream) HCHECK(h, hipStreamSynchronize(h->comm_stream));
   return 0;
@@ -655,7 +664,7 @@ int pion_gpu_synchronize(void *handle)
 
 int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double *states)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   hipFree(h->dwind_idx);
   hipFree(h->dwind_state);
   h->dwind_idx = nullptr;
@@ -678,7 +687,7 @@ int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double 
 
 int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   const pion_gpu_config &cfg = h->cfg;
   const GridDesc &g = h->g;
   if (cfg.ndim != 3 || cfg.eqntype != PION_EQEUL || !jetstate) {
@@ -714,7 +723,7 @@ int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
 
 int pion_gpu_set_cooling_tables(void *handle, int nT, const double *T, const double *tabs, const double *slopes)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   if (nT < 2) return PION_GPU_EINVAL;
   hipFree(h->dcoolT);
   hipFree(h->dcooltab);
@@ -735,7 +744,7 @@ int pion_gpu_set_cooling_tables(void *handle, int nT, const double *T, const dou
 
 int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, int assign)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   const pion_gpu_config &cfg = h->cfg;
   const GridDesc &g = h->g;
   const bool full = (cstep == maxstep);
@@ -845,7 +854,7 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
 
 int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   DtArgs a;
   a.g = h->g;
   a.P = h->dP;
@@ -884,7 +893,7 @@ int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
 
 int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   h->glm_chyp = h->cfg.cfl * dx / dt;  // GLMsetPsiSpeed(FV_cfl*delx/delt, cr)
   h->glm_cr = cr;
   return 0;
@@ -1023,7 +1032,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
 
 int pion_gpu_stage_part(void *handle, double dt_stage, int space_ooa, int is_full_step, int part)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   const int nz = h->g.ng[2], nb = h->g.nbc[2];
   if (part == PION_STAGE_WHOLE) {
     if (int rc = order_after_unpack(h)) return rc;
@@ -1050,7 +1059,7 @@ int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_ste
 
 int pion_gpu_advance_time(void *handle, double dt, double simtime)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   int rc;
   if (h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1) {
     if ((rc = pion_gpu_stage(handle, dt, 1, 1))) return rc;
@@ -1068,7 +1077,7 @@ int pion_gpu_advance_time(void *handle, double dt, double simtime)
 
 long pion_gpu_halo_count(void *handle)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   return (long)h->cfg.nvar * h->g.nbc[2] * h->g.nga[0] * h->g.nga[1];
 }
 static int halo_go(Handle *h, int which, int face, void *dbuf, int pack)
@@ -1093,13 +1102,13 @@ static int halo_go(Handle *h, int which, int face, void *dbuf, int pack)
   }
   return 0;
 }
-int pion_gpu_pack_halo(void *handle, int which, int face, void *dbuf) { return halo_go((Handle *)handle, which, face, dbuf, 1); }
-int pion_gpu_unpack_halo(void *handle, int which, int face, void *dbuf) { return halo_go((Handle *)handle, which, face, dbuf, 0); }
+int pion_gpu_pack_halo(void *handle, int which, int face, void *dbuf) { return halo_go(use(handle), which, face, dbuf, 1); }
+int pion_gpu_unpack_halo(void *handle, int which, int face, void *dbuf) { return halo_go(use(handle), which, face, dbuf, 0); }
 
 int pion_gpu_interface_flux(void *handle, int n, int axis, double dt, const double *Pl, const double *Pr,
                             const double *aux, double *F, double *Pstar)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   const int nv = h->cfg.nvar;
   double *dl, *dr, *da, *df, *dp;
   const size_t nb = sizeof(double) * (size_t)n * nv;
@@ -1195,16 +1204,16 @@ static int cool_go(Handle *h, int n, double dt, const double *Pin, double *Pout,
 }
 int pion_gpu_cooling_update(void *handle, int n, double dt, const double *P_in, double *P_out)
 {
-  return cool_go((Handle *)handle, n, dt, P_in, P_out, nullptr, nullptr, nullptr);
+  return cool_go(use(handle), n, dt, P_in, P_out, nullptr, nullptr, nullptr);
 }
 int pion_gpu_cooling_edot(void *handle, int n, const double *rho, const double *T, double *edot)
 {
-  return cool_go((Handle *)handle, n, 0.0, nullptr, nullptr, rho, T, edot);
+  return cool_go(use(handle), n, 0.0, nullptr, nullptr, rho, T, edot);
 }
 
 int pion_gpu_enable_timing(void *handle, int on)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   h->timing = on != 0;
   for (int s = 0; s < 4; s++) {
     for (hipEvent_t e : h->ev[s]) hipEventDestroy(e);
@@ -1214,7 +1223,7 @@ int pion_gpu_enable_timing(void *handle, int on)
 }
 int pion_gpu_get_timing(void *handle, double *out, int n)
 {
-  Handle *h = (Handle *)handle;
+  Handle *h = use(handle);
   HCHECK(h, hipStreamSynchronize(h->stream));
   for (int s = 0; s < 4 && s < n; s++) {
     double tot = 0.0;
