@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-parity kernels (no FMA contraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=64)
+    ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3"],
+                    help="m1 (default, the headline): MHD blast; m2: 3-D Euler Roe-CV octant Sedov blast (SURVEY 8d); "
+                         "m3: Wind3D single level, FVS + cooling 8 + stellar wind.  m2/m3 are extra rows for "
+                         "DESIGN.md, single GPU only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
                          "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
@@ -111,18 +115,37 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
 
-    cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
     n = args.n
-    cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
-    cfg_g.dx = 1.0 / n
-    cfg = slab.slab_config(cfg_g, rank, world)
-    P = problems.fill_mhd_blastwave(cfg)
-
-    sim = lib.GpuSim(cfg, local_rank)
+    wl_name = None
+    dt_lim = None
+    if args.workload == "m1":
+        cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
+        cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
+        cfg_g.dx = 1.0 / n
+        cfg = slab.slab_config(cfg_g, rank, world)
+        P = problems.fill_mhd_blastwave(cfg)
+        sim = lib.GpuSim(cfg, local_rank)
+    else:
+        if world != 1:
+            raise SystemExit("--workload m2/m3: single GPU only")
+        if args.workload == "m2":
+            cfg, P = problems.hd_blast_octant(n, 3, solver=abi.FLUX_RSroe, strict_fp=args.strict, nzones=n / 32.0)
+            wl_name = "M2: 3-D Euler octant Sedov blast %d^3, Roe-CV + FKJ98 0.1, reflecting/outflow, OA2/OA2" % n
+            sim = lib.GpuSim(cfg, local_rank)
+        else:
+            from pion_amd import cooling
+            cfg, P, (widx, wst), dt_lim = problems.wind3d(n, strict_fp=args.strict)
+            wl_name = ("M3: Wind3D single level %d^3, Euler + tracer, FVS + FKJ98 0.15, cooling 8, stellar wind, "
+                       "reflecting/one-way, OA2/OA2" % n)
+            sim = lib.GpuSim(cfg, local_rank)
+            sim.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
+            sim.set_wind_cells(widx, wst)
+        eq = cfg.eqntype
     if world > 1:
         comm = slab.SlabComm(rank, world, True, sim.halo_count(), torch.device("cuda", local_rank))
         comm.use_streams(sim)   # exchange under the interior part of each stage, no host waits
     sc = driver.SimControl(sim, cfg, comm=comm)
+    sc.first_step_dt_limit = dt_lim
     sc.init(P)
     del P
 
@@ -168,7 +191,8 @@ def main():
         # when it is for this workload (512^3, GLM, fast mode, 1 GPU); otherwise null.
         traffic = None
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if world == 1 and n == 512 and eq == abi.EQGLM and not args.strict and os.path.exists(tfile):
+        if (world == 1 and n == 512 and eq == abi.EQGLM and not args.strict and args.workload == "m1"
+                and os.path.exists(tfile)):
             with open(tfile) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
         out = {
@@ -176,7 +200,7 @@ def main():
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
+            "config": {"workload": wl_name or "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
                                    % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
                        "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": "none" if world == 1 else
                        ("RCCL P2P" if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"),
@@ -184,11 +208,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
-                         "kernel": "k_stage_rows<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows<MHD,0,HLLD>",
+                         "kernel": {"m1": "k_stage_rows<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows<MHD,0,HLLD>",
+                                    "m2": "k_stage_rows<EUL,0,Roe-CV>", "m3": "k_stage_rows<EUL,1,FVS>"}[args.workload],
                          "kernel_ms": stage_ms, "launches_per_stage": tm["stage_n"] / (2.0 * args.steps), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "m1":
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, eq, solver)
         print(json.dumps(out))
     sim.close()

@@ -258,3 +258,16 @@ def test_hlld_with_hcorrection_instances_3d(eq, ntr, strict, monkeypatch):
         run_pair(cfg, P, 2)
     else:
         _fast_rows_vs_cell(cfg, P, 2, monkeypatch)
+
+
+@pytest.mark.parametrize("strict", [1, 0])
+@pytest.mark.parametrize("ntr", [0, 1, 2])
+def test_hd_roe_with_hcorrection_instances_3d(ntr, strict, monkeypatch):
+    """Euler Roe-CV is specialised like MHD HLLD (stage_rows_go): the non-plain instances"""
+    cfg0, P0 = problems.hd_blast_octant(14, 3, solver=abi.FLUX_RSroe, artvisc=abi.AV_HCORR_FKJ98, strict_fp=strict,
+                                        nzones=3.0)
+    cfg, P = _with_tracers(cfg0, P0, ntr)
+    if strict:
+        run_pair(cfg, P, 2)
+    else:
+        _fast_rows_vs_cell(cfg, P, 2, monkeypatch)
