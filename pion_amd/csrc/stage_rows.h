@@ -393,12 +393,13 @@ static int stage_rows_go(const StageArgs &a0, hipStream_t s)
   const long ntiles = (long)ntx * nyg * nzc;
   const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
   const size_t shmem = sizeof(double) * 4 * R * (2 * NV) * 64;
-  // compile-time spatial order for the MHD HLLD and the Euler Roe-CV instances (the production
-  // configurations M1 and M2; both specialised
+  // compile-time spatial order for the MHD HLLD, Euler Roe-CV and Euler FVS instances (the production
+  // configurations M1, M2, M3; both specialised
   // kernels run in every OA2/OA2 step, so tests/test_gpu_parity.py::test_every_mhd_instantiation_3d covers
   // them); one more specialised instance of another solver aborted on the device in testing, like the
   // other per-instance miscompiles listed in the Makefile, so the rest keep the run-time form
-  constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL) || (SOLVER == FLUX_RSroe && EQ == EQEUL);
+  constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)
+                              || ((SOLVER == FLUX_RSroe || SOLVER == FLUX_FVS) && EQ == EQEUL);
   if constexpr (specialise) {
     const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
                         && a.fc.artvisc != AV_HCORR_FKJ98);
