@@ -133,6 +133,22 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         load_rot<NV, MHD>(a.S, nc, 1, c + far * sy, yfar);
       }
       load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
+      // small values the y and z tasks would otherwise fetch right before their solve (a dependent
+      // L2 round trip each): B_n / psi of the lower neighbours and the HLLD -> HLL switch flags
+      double ybnm = 0.0, ysim = 0.0, zbnm = 0.0, zsim = 0.0;
+      unsigned hf = 0;   // bit 0: this cell, 1: +x, 2: +y, 3: +z
+      if constexpr (MHD) {
+        zbnm = a.S[(long)rotvar<MHD>(2, qBN) * nc + c - sz];
+        if constexpr (EQ == EQGLM) zsim = a.S[(long)qSI * nc + c - sz];
+        if (!prime) {
+          ybnm = a.S[(long)rotvar<MHD>(1, qBN) * nc + c - sy];
+          if constexpr (EQ == EQGLM) ysim = a.S[(long)qSI * nc + c - sy];
+        }
+        if constexpr (SOLVER == FLUX_RS_HLLD) {
+          hf = (unsigned)a.hllflag[c] | ((unsigned)a.hllflag[c + sz] << 3);
+          if (!prime) hf |= ((unsigned)a.hllflag[c + 1] << 1) | ((unsigned)a.hllflag[c + sy] << 2);
+        }
+      }
 
       if (!PLAIN && !prime && a.cooling != 0) {
         if (fl & 4) {
@@ -252,10 +268,10 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           }
           if constexpr (MHD) {
             bnp = qp1[qBN];
-            bnm = a.S[(long)rotvar<MHD>(1, qBN) * nc + c - sy];
+            bnm = ybnm;
             if constexpr (EQ == EQGLM) {
               sip = qp1[qSI];
-              sim = a.S[(long)qSI * nc + c - sy];
+              sim = ysim;
             }
           }
         }
@@ -294,10 +310,10 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           }
           if constexpr (MHD) {
             bnp = qp1[qBN];
-            bnm = a.S[(long)rotvar<MHD>(2, qBN) * nc + c - sz];
+            bnm = zbnm;
             if constexpr (EQ == EQGLM) {
               sip = qp1[qSI];
-              sim = a.S[(long)qSI * nc + c - sz];
+              sim = zsim;
             }
           }
         }
@@ -305,7 +321,12 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         double hc_eta = 0.0;
         if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
         bool use_hll = false;
-        if constexpr (MHD && SOLVER == FLUX_RS_HLLD) use_hll = (a.hllflag[cl] | a.hllflag[cl + st]) != 0;
+        if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
+          if (t == 0) use_hll = (hf & 3u) != 0;
+          else if (t == 1) use_hll = (a.hllflag[cl] | (hf & 1u)) != 0;
+          else if (t == 2) use_hll = (hf & 5u) != 0;
+          else use_hll = (hf & 9u) != 0;
+        }
         FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 
         if (t == 0) {
