@@ -56,6 +56,7 @@ struct StageArgs {
   int zchunk;         // planes per wavefront in the marching kernels
   int rows;           // y-rows per wavefront in k_stage_rows
   int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows; others: whole grid)
+  int kz2, kz3;       // and a second strip [kz2,kz3) (empty when kz3 <= kz2): the two z-boundary strips
   unsigned long long *dtres;  // k_stage_rows, full step: min t_dyn / t_mp bits of the new state (or null)
   double cfl;
   int dt_mp;          // also reduce the cooling time (EP.MP_timestep_limit)

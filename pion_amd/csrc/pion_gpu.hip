@@ -908,8 +908,9 @@ static bool stage_can_split(const Handle *h)
          && h->g.ng[2] > 2 * h->g.nbc[2] && !(h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1);
 }
 
+// planes [kz0,kz1) and, if kz3 > kz2, also [kz2,kz3) (the two z-boundary strips go out as ONE launch)
 static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_step, int kz0, int kz1,
-                        bool first, bool last)
+                        bool first, bool last, int kz2 = 0, int kz3 = 0)
 {
   const pion_gpu_config &cfg = h->cfg;
   if (cfg.cooling != 0 && !h->have_tables) {
@@ -952,6 +953,13 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     }
     time_begin(h, 1);
     rc = cfg.strict_fp ? fp_strict::launch_prepass(p, h->stream) : fp_fast::launch_prepass(p, h->stream);
+    if (rc == 0 && kz3 > kz2) {
+      // second strip (the upper z boundary): its own plane range of flags
+      const int nb = h->g.nbc[2], nz = h->g.ng[2];
+      p.c0 = (long)(nz - nb + 1 + nb) * h->g.sz;
+      p.c1 = (long)(nz + 1 + nb) * h->g.sz;
+      rc = cfg.strict_fp ? fp_strict::launch_prepass(p, h->stream) : fp_fast::launch_prepass(p, h->stream);
+    }
     time_end(h, 1);
     if (rc != 0) {
       h->err = "prepass launch failed";
@@ -992,6 +1000,8 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.zchunk = h->zchunk;
   a.kz0 = kz0;
   a.kz1 = kz1;
+  a.kz2 = kz2;
+  a.kz3 = (kz3 > kz2) ? kz3 : kz2;
   if (a.zchunk <= 0) {
     // planes per wavefront: long chunks amortise the priming plane, but keep >= ~4 wavefronts per SIMD
     // (1024 SIMDs) in flight so that the tail of the launch stays short
@@ -1047,9 +1057,7 @@ int pion_gpu_stage_part(void *handle, double dt_stage, int space_ooa, int is_ful
   // the z ghost planes must have arrived: order the compute stream after the last unpack
   if (int rc = order_after_unpack(h)) return rc;
   if (!split) return stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nz, true, true);
-  int rc = stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nb, false, false);
-  if (rc) return rc;
-  return stage_launch(h, dt_stage, space_ooa, is_full_step, nz - nb, nz, false, true);
+  return stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nb, false, true, nz - nb, nz);
 }
 
 int pion_gpu_stage(void *handle, double dt_stage, int space_ooa, int is_full_step)

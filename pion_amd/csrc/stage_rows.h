@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
   const int R = a.rows;
   const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
   const int nyg = (a.g.ng[1] + R - 1) / R;
-  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
+  const int nzc1 = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
+  const int nzc = nzc1 + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;   // chunks of both strips
   const long ntiles = (long)ntx * nyg * nzc;
   // PION_WAVE_UNIFORM (strict build, see Makefile): readfirstlane tells the compiler the wavefront
   // number -- and the tile, row and plane loops that follow from it -- is uniform, so they live in SGPRs
@@ -52,8 +53,9 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
   if (ix > a.g.ng[0]) ix = a.g.ng[0];
   const int j0 = jg * R;
   const int nrows = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
-  const int k0 = a.kz0 + cz * a.zchunk;
-  const int k1 = (k0 + a.zchunk < a.kz1) ? k0 + a.zchunk : a.kz1;
+  const int k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
+  const int kend = (cz < nzc1) ? a.kz1 : a.kz3;
+  const int k1 = (k0 + a.zchunk < kend) ? k0 + a.zchunk : kend;
 
   const long nc = a.g.ncell, sy = a.g.sy, sz = a.g.sz;
   const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
@@ -410,7 +412,7 @@ static int stage_rows_go(const StageArgs &a0, hipStream_t s)
   const int R = a.rows;
   const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
   const int nyg = (a.g.ng[1] + R - 1) / R;
-  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
+  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)ntx * nyg * nzc;
   const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
   const size_t shmem = sizeof(double) * 4 * R * (2 * NV) * 64;
