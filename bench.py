@@ -76,8 +76,8 @@ def cpu_baseline(n, eqntype, solver, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", "--grid", dest="n", type=int, default=512, help="cells per axis (headline: 512); use --grid under torch.distributed.run, whose own parser finds --n ambiguous")
     ap.add_argument("--eqn", default="glm", choices=["glm", "mhd"])
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-parity kernels (no FMA contraction)")
