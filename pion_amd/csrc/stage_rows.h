@@ -20,6 +20,23 @@
 #ifndef PION_ROWS_ATTR
 #define PION_ROWS_ATTR
 #endif
+// x/y tiling of one plane chunk, shared by the kernel and its launcher
+struct RowsTiling {
+  int ntx_full, rem, spw, nyg, nfull, nrem, per_chunk;
+};
+__host__ __device__ inline RowsTiling rows_tiling(const StageArgs &a)
+{
+  RowsTiling t;
+  t.nyg = (a.g.ng[1] + a.rows - 1) / a.rows;
+  t.ntx_full = a.g.ng[0] / PION_MARCH_XT;
+  t.rem = a.g.ng[0] - t.ntx_full * PION_MARCH_XT;
+  t.spw = (t.rem > 0) ? 64 / (t.rem + 2) : 0;   // row groups per remainder wavefront
+  t.nfull = t.ntx_full * t.nyg;
+  t.nrem = (t.rem > 0) ? (t.nyg + t.spw - 1) / t.spw : 0;
+  t.per_chunk = t.nfull + t.nrem;
+  return t;
+}
+
 template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN>
 __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageArgs a)
 {
@@ -30,11 +47,15 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
   extern __shared__ double lds[];
 
   const int R = a.rows;
-  const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
-  const int nyg = (a.g.ng[1] + R - 1) / R;
+  // x tiling: full tiles of PION_MARCH_XT cells, one wavefront each; the remaining rem cells of a row
+  // (16 of 512) would leave most of a wavefront idle, so a "remainder" wavefront packs the remainders
+  // of spw consecutive row groups side by side, each in a segment of rem+2 lanes with its own two
+  // halo lanes (the x shuffles only ever cross a segment boundary into a halo lane)
+  const RowsTiling tl = rows_tiling(a);
+  const int nyg = tl.nyg;
   const int nzc1 = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
   const int nzc = nzc1 + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;   // chunks of both strips
-  const long ntiles = (long)ntx * nyg * nzc;
+  const long ntiles = (long)tl.per_chunk * nzc;
   // PION_WAVE_UNIFORM (strict build, see Makefile): readfirstlane tells the compiler the wavefront
   // number -- and the tile, row and plane loops that follow from it -- is uniform, so they live in SGPRs
   // and branch on the scalar unit.  Measured 1 ms/launch slower at 512^3 (more SGPR spill traffic), so
@@ -46,13 +67,30 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
 #endif
   const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
   if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
-  const int tx = (int)(tile % ntx), jg = (int)((tile / ntx) % nyg), cz = (int)(tile / ((long)ntx * nyg));
+  const int cz = (int)(tile / tl.per_chunk), tt = (int)(tile % tl.per_chunk);
   const int lane = threadIdx.x & 63;
-  int ix = tx * PION_MARCH_XT - 1 + lane;
-  const bool writer = (lane >= 1 && lane <= PION_MARCH_XT && ix < a.g.ng[0]);
+  int ix, jg, jg_first;   // jg: this LANE's row group; jg_first: the wavefront's first (uniform)
+  bool writer;
+  if (tt < tl.nfull) {
+    const int tx = tt % tl.ntx_full;
+    jg = jg_first = tt / tl.ntx_full;
+    ix = tx * PION_MARCH_XT - 1 + lane;
+    writer = (lane >= 1 && lane <= PION_MARCH_XT && ix < a.g.ng[0]);
+  }
+  else {
+    const int seg = lane / (tl.rem + 2), pos = lane % (tl.rem + 2);
+    jg_first = (tt - tl.nfull) * tl.spw;
+    jg = jg_first + seg;
+    ix = tl.ntx_full * PION_MARCH_XT - 1 + pos;
+    writer = (seg < tl.spw && jg < nyg && pos >= 1 && pos <= tl.rem);
+    if (jg >= nyg) jg = nyg - 1;   // idle lanes redo the last group, in bounds, and write nothing
+  }
   if (ix > a.g.ng[0]) ix = a.g.ng[0];
   const int j0 = jg * R;
-  const int nrows = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
+  // rows of the wavefront's first group (the longest: only the last group of a plane can be short) bound
+  // the row loop; a lane whose own group is shorter repeats its last row (rr) and is masked out (row_ok)
+  const int nrows = (jg_first * R + R <= a.g.ng[1]) ? R : a.g.ng[1] - jg_first * R;
+  const int nrows_l = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
   const int k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
   const int kend = (cz < nzc1) ? a.kz1 : a.kz3;
   const int k1 = (k0 + a.zchunk < kend) ? k0 + a.zchunk : kend;
@@ -82,7 +120,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
   // z slope of the priming plane k0-1 for every row
 #pragma unroll 1
   for (int r = 0; r < nrows; r++) {
-    const long c = crow0 + sy * r;
+    const long c = crow0 + sy * ((r < nrows_l) ? r : nrows_l - 1);
     double qa[NV], qb[NV], qc[NV], s[NV];
     load_rot<NV, MHD>(a.S, nc, 2, c - sz, qa);
     load_rot<NV, MHD>(a.S, nc, 2, c, qb);
@@ -105,7 +143,8 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
 
 #pragma unroll 1
     for (int r = 0; r < nrows; r++) {
-      const long c = crow0 + sy * r + sz * (k - (k0 - 1));
+      const bool row_ok = (r < nrows_l);
+      const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
       // Load order matters: a wavefront's loads return in order and only one wavefront runs per SIMD,
       // so a wait for any load also waits for every older one.  First what the x task needs at once
       // (L1/L2 hits: this row was a y neighbour of the previous one), THEN the loads that go to HBM and
@@ -365,7 +404,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         }
       }
 
-      if (!prime && writer) {
+      if (!prime && writer && row_ok) {
         double Pf[NV];
         if (!(fl & 4) || !(fl & 16)) {
 #pragma unroll
@@ -410,10 +449,8 @@ static int stage_rows_go(const StageArgs &a0, hipStream_t s)
   if (a.rows > rmax) a.rows = rmax;
   if (a.rows < 1) a.rows = 1;
   const int R = a.rows;
-  const int ntx = (a.g.ng[0] + PION_MARCH_XT - 1) / PION_MARCH_XT;
-  const int nyg = (a.g.ng[1] + R - 1) / R;
   const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
-  const long ntiles = (long)ntx * nyg * nzc;
+  const long ntiles = (long)rows_tiling(a).per_chunk * nzc;
   const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
   const size_t shmem = sizeof(double) * 4 * R * (2 * NV) * 64;
   // compile-time spatial order for the MHD HLLD, Euler Roe-CV and Euler FVS instances (the production
