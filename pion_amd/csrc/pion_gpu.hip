@@ -235,6 +235,7 @@ struct Handle {
   pion_gpu_config cfg;
   GridDesc g;
   int device = 0;
+  int ncu = 0;            // compute units of the device (launch shaping)
   hipStream_t stream = 0;
   hipStream_t comm_stream = 0;     // pack/unpack of the z halo (0: the compute stream)
   hipEvent_t ev_packed_src = nullptr, ev_unpacked = nullptr;
@@ -400,6 +401,10 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (hipSetDevice(device) != hipSuccess) {
     delete h;
     return PION_GPU_EDEVICE;
+  }
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) h->ncu = ncu;
   }
   GridDesc &g = h->g;
   g.ndim = cfg->ndim;
@@ -1003,11 +1008,33 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.kz2 = kz2;
   a.kz3 = (kz3 > kz2) ? kz3 : kz2;
   if (a.zchunk <= 0) {
-    // planes per wavefront: long chunks amortise the priming plane, but keep >= ~4 wavefronts per SIMD
-    // (1024 SIMDs) in flight so that the tail of the launch stays short
-    const long per_plane_chunk = (long)((h->g.ng[0] + 61) / 62) * ((h->g.ng[1] + a.rows - 1) / a.rows);
-    a.zchunk = 64;
-    while (a.zchunk > 8 && per_plane_chunk * ((kz1 - kz0 + a.zchunk - 1) / a.zchunk) < 4096) a.zchunk /= 2;
+    // Planes per wavefront.  Every wavefront takes about (zchunk + 1 priming plane) plane visits, one
+    // wavefront runs per SIMD, and a launch proceeds in rounds of (4 x CUs) equal wavefronts, so its cost
+    // is ceil(wavefronts / slots) x (zchunk + 1): pick the chunk that minimises it (512^3 on 256 CUs:
+    // 32 planes, 17 rounds of 33 visits, instead of 64 planes, 9 rounds of 65: measured 22.9 -> 21.8 ms).
+    const int nv = cfg.nvar;
+    int rows = a.rows;
+    const int rmax = (int)((160 * 1024) / (sizeof(double) * 4 * (2 * nv) * 64));
+    if (rows > rmax) rows = rmax;
+    if (rows < 1) rows = 1;
+    const int nyg = (h->g.ng[1] + rows - 1) / rows;
+    const int ntx_full = h->g.ng[0] / 62, rem = h->g.ng[0] - ntx_full * 62;
+    const int spw = (rem > 0) ? 64 / (rem + 2) : 0;
+    const long per_chunk = (long)ntx_full * nyg + ((rem > 0) ? (nyg + spw - 1) / spw : 0);
+    const long slots = 4L * (h->ncu > 0 ? h->ncu : 256);
+    const int np = kz1 - kz0;
+    long best_cost = -1;
+    a.zchunk = 8;
+    for (int zc = 8; zc <= 128; zc++) {
+      const long nzc = (np + zc - 1) / zc;
+      const long rounds = (per_chunk * nzc + slots - 1) / slots;
+      const int longest = (zc < np ? zc : np) + 1;
+      const long cost = rounds * longest;
+      if (best_cost < 0 || cost <= best_cost) {   // ties: the longer chunk (fewer priming planes)
+        best_cost = cost;
+        a.zchunk = zc;
+      }
+    }
   }
   // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
   // (second-order stages only: the first-order instances of k_stage_rows carry no reduction code)
