@@ -606,13 +606,22 @@ const char *stage_kernel_name(int, int, int) { return "k_stage"; }
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
 {
-  const long c = a.c0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // 3-D launch (64 x 4 threads; grid = x tiles, y tiles, planes of [c0,c1)): the cell coordinates come
+  // from the block and thread indices -- the flat-index form spent more on 64-bit div/mod than on physics
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: give every XCD a contiguous
+  // range of (x,y,z) tiles (z slowest) so that the y and z neighbours it reads are lines its own L2 holds
   const long nc = a.g.ncell;
-  if (c >= a.c1) return;
+  const unsigned gx = (a.g.nga[0] + 63) / 64, gy = (a.g.nga[1] + 3) / 4;
+  const unsigned npl = (unsigned)((a.c1 - a.c0) / ((long)a.g.nga[0] * a.g.nga[1]));
+  const unsigned ntile = gx * gy * npl;
+  const unsigned t = (unsigned)xcd_tile(blockIdx.x, ntile);
+  if (t >= ntile) return;
   int i[3];
-  i[0] = (int)(c % a.g.nga[0]);
-  i[1] = (int)((c / a.g.nga[0]) % a.g.nga[1]);
-  i[2] = (int)(c / ((long)a.g.nga[0] * a.g.nga[1]));
+  i[0] = (int)((t % gx) * 64 + (threadIdx.x & 63));
+  i[1] = (int)(((t / gx) % gy) * 4 + (threadIdx.x >> 6));
+  i[2] = (int)(a.c0 / ((long)a.g.nga[0] * a.g.nga[1])) + (int)(t / (gx * gy));
+  if (i[0] >= a.g.nga[0] || i[1] >= a.g.nga[1]) return;
+  const long c = (long)i[0] + a.g.sy * i[1] + a.g.sz * i[2];
   const double dx = a.g.dx;
   double divv = 0.0, gradp = 0.0;
   for (int v = 0; v < a.g.ndim; v++) {
@@ -717,7 +726,13 @@ __global__ __launch_bounds__(256) void k_prepass_hcorr(const PrepassArgs a)
 int launch_prepass(const PrepassArgs &a, hipStream_t s)
 {
   const unsigned nb = (unsigned)((a.c1 - a.c0 + 255) / 256);
-  if (a.hllflag) hipLaunchKernelGGL(k_prepass_hlld, dim3(nb), dim3(256), 0, s, a);
+  if (a.hllflag) {
+    // [c0,c1) is a whole number of planes (pion_gpu.hip)
+    const long plane = (long)a.g.nga[0] * a.g.nga[1];
+    const unsigned npl = (unsigned)((a.c1 - a.c0) / plane);
+    const unsigned ntile = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * npl;
+    hipLaunchKernelGGL(k_prepass_hlld, dim3(((ntile + 7) / 8) * 8), dim3(256), 0, s, a);
+  }
   if (a.eta) hipLaunchKernelGGL((k_prepass_hcorr<8>), dim3(nb), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
