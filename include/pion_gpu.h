@@ -164,7 +164,9 @@ int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double 
  * branch :170-201, update :212-262) with JetParams (sim_params.h:331-341): every XN ghost cell of an
  * on-grid (y,z) column whose centre lies within jetradius*dx of the x axis holds `jetstate`
  * (rho, p_g, v, then tracers), re-imposed after the external boundaries at every boundary update.
- * 3-D Euler only, as in the reference (MHD jets there need 2-D cylindrical coordinates). */
+ * 3-D Cartesian (Euler only, as in the reference) or 2-D cylindrical: there the first jetradius rows above
+ * the axis, with B = (jetstate[BX], 0, jetstate[BY]) for MHD (:74-83; the radial JETPROFILE of the
+ * assignment is overwritten by the uniform state in every update, so it is not reproduced). */
 int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate);
 
 /* mp_only_cooling look-up tables (microphysics/mp_only_cooling.cpp:528-579):

@@ -695,19 +695,40 @@ int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
   Handle *h = use(handle);
   const pion_gpu_config &cfg = h->cfg;
   const GridDesc &g = h->g;
-  if (cfg.ndim != 3 || cfg.eqntype != PION_EQEUL || !jetstate) {
-    h->err = "jet boundary: 3-D Euler only (jet_boundaries.cpp:88-91,203-206)";
+  const bool cart3d = (cfg.ndim == 3 && cfg.coord_sys == 1 && cfg.eqntype == PION_EQEUL);
+  const bool cyl2d = (cfg.ndim == 2 && cfg.coord_sys == 2);
+  if ((!cart3d && !cyl2d) || !jetstate) {
+    h->err = "jet boundary: 3-D Cartesian Euler or 2-D cylindrical only (jet_boundaries.cpp:88-91,203-206)";
     return PION_GPU_EINVAL;
   }
-  // BC_assign_JETBC, 3-D Cartesian (jet_boundaries.cpp:170-201)
   std::vector<long> idx;
-  const double jr = jetradius * g.dx;
-  for (int iz = 0; iz < g.ng[2]; iz++)
-    for (int iy = 0; iy < g.ng[1]; iy++) {
-      const double y = g.xmin[1] + (2 * iy + 1) * (0.5 * g.dx), z = g.xmin[2] + (2 * iz + 1) * (0.5 * g.dx);
-      if (sqrt(y * y + z * z) <= jr)
-        for (int k = 1; k <= g.nbc[0]; k++) idx.push_back(cell_id(g, -k, iy, iz));
+  if (cart3d) {
+    // BC_assign_JETBC, 3-D Cartesian (jet_boundaries.cpp:170-201)
+    const double jr = jetradius * g.dx;
+    for (int iz = 0; iz < g.ng[2]; iz++)
+      for (int iy = 0; iy < g.ng[1]; iy++) {
+        const double y = g.xmin[1] + (2 * iy + 1) * (0.5 * g.dx), z = g.xmin[2] + (2 * iz + 1) * (0.5 * g.dx);
+        if (sqrt(y * y + z * z) <= jr)
+          for (int k = 1; k <= g.nbc[0]; k++) idx.push_back(cell_id(g, -k, iy, iz));
+      }
+  }
+  else {
+    // 2-D axisymmetric (:96-168): the first jetradius rows above the axis; the profile written at
+    // assignment does not survive the first update (:212-262), so the uniform state is all there is
+    if (jetradius > g.ng[1]) {
+      h->err = "Not enough cells for jet";
+      return PION_GPU_EINVAL;
     }
+    for (int iy = 0; iy < jetradius; iy++)
+      for (int k = 1; k <= g.nbc[0]; k++) idx.push_back(cell_id(g, -k, iy, 0));
+  }
+  // refval (jet_boundaries.cpp:60-93): 2-D MHD keeps B along the axis and the toroidal component
+  std::vector<double> rv(jetstate, jetstate + cfg.nvar);
+  if (cfg.eqntype != PION_EQEUL) {
+    rv[5] = jetstate[5];
+    rv[6] = 0.0;
+    rv[7] = jetstate[6];
+  }
   hipFree(h->djet_idx);
   hipFree(h->djet_state);
   h->djet_idx = nullptr;
@@ -716,7 +737,7 @@ int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
   // k_wind takes one state per cell
   std::vector<double> st((size_t)h->njet * cfg.nvar);
   for (long k = 0; k < h->njet; k++)
-    for (int v = 0; v < cfg.nvar; v++) st[(size_t)k * cfg.nvar + v] = jetstate[v];
+    for (int v = 0; v < cfg.nvar; v++) st[(size_t)k * cfg.nvar + v] = rv[v];
   if (h->njet > 0) {
     HCHECK(h, hipMalloc(&h->djet_idx, sizeof(long) * h->njet));
     HCHECK(h, hipMalloc(&h->djet_state, sizeof(double) * st.size()));

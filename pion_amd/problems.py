@@ -179,6 +179,27 @@ def jet3d(n, solver=abi.FLUX_RSroe, jetradius=3, strict_fp=0):
     return cfg, P, (jetradius, jetstate)
 
 
+def jet_axi2d(n, eqntype=abi.EQGLM, solver=abi.FLUX_RS_HLLD, jetradius=4, strict_fp=0):
+    """2-D axisymmetric (z,R) magnetised jet (ics/jet.cpp, boundaries/jet_boundaries.cpp 2-D branch): uniform
+    ambient medium with an axial field, axisymmetric BC on the axis, outflow elsewhere, internal JETBC on XN."""
+    nvb = {abi.EQEUL: 5, abi.EQMHD: 8, abi.EQGLM: 9}[eqntype]
+    ref = [1.0, 1.0, 1.0, 1.0, 1.0] + ([1.0, 1.0, 1.0] if nvb >= 8 else []) + ([1.0] if nvb == 9 else []) + [1.0]
+    cfg = abi.make_config(2, [n, n // 2], eqntype, solver, ntracer=1, artvisc=abi.AV_FKJ98_1D, etav=0.15,
+                          gamma=5.0 / 3.0, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(1.0, 0.5, 0.0),
+                          bcs=["outflow", "outflow", "axisymmetric", "outflow"], refvec=ref, strict_fp=strict_fp,
+                          coord_sys=2)
+    P = alloc(cfg)
+    P[abi.RO] = 1.0
+    P[abi.PG] = 1.0
+    js = np.zeros(cfg.nvar)
+    js[abi.RO], js[abi.PG], js[abi.VX] = 0.5, 1.0, 2.0
+    if nvb >= 8:
+        P[abi.BX] = 0.3
+        js[abi.BX], js[abi.BY] = 0.3, 0.2   # axial field, toroidal field (JP.jetstate[BY] -> B_theta)
+    js[nvb] = 1.0
+    return cfg, P, (jetradius, js)
+
+
 def double_mach_reflection(nx, solver=abi.FLUX_RSroe, strict_fp=0):
     """test_problems/double_Mach_reflection/params_DMR_n130.txt scaled to nx cells in x
     (aspect 3.25:1): IC_basic_tests::setup_DoubleMachRef (ics/basic_tests.cpp:736)."""
