@@ -70,6 +70,8 @@ extern "C" {
 #define PION_BC_STWIND 9  /* internal: stellar-wind cells (fixed per-cell state) */
 #define PION_BC_SLAB 10   /* z face owned by a neighbouring GPU (halo exchange) */
 #define PION_BC_JET 11    /* internal: jet inflow cells on the XN face (pion_gpu_set_jet) */
+#define PION_BC_JETREFLECT 13   /* reflecting wall behind a jet: v_n and the TANGENTIAL field change sign
+                                 * (jetreflect_boundaries.cpp:32-62) */
 #define PION_BC_AXISYMMETRIC 12 /* R = 0 axis of a cylindrical (z,R) grid, face YN only (axisymmetric_boundaries.cpp) */
 
 /* cooling functions of mp_only_cooling (microphysics/mp_only_cooling.h) */

@@ -42,6 +42,7 @@
 #include "boundaries/double_Mach_ref_boundaries.h"
 #include "boundaries/jet_boundaries.h"
 #include "boundaries/axisymmetric_boundaries.h"
+#include "boundaries/jetreflect_boundaries.h"
 
 #include "../include/pion_gpu.h"
 
@@ -318,7 +319,8 @@ struct RefSim : public periodic_bc,
                 public fixed_bc,
                 public double_Mach_ref_bc,
                 public jet_bc,
-                public axisymmetric_bc {
+                public axisymmetric_bc,
+                public jetreflect_bc {
   pion_gpu_config cfg;
   SimParams par;
   HarnessGrid *grid;
@@ -339,6 +341,7 @@ struct RefSim : public periodic_bc,
       case PION_BC_DMACH: return DMACH;
       case PION_BC_DMACH2: return DMACH2;
       case PION_BC_AXISYMMETRIC: return AXISYMMETRIC;
+      case PION_BC_JETREFLECT: return JETREFLECT;
       default: return -1;
     }
   }
@@ -522,6 +525,7 @@ struct RefSim : public periodic_bc,
         case INFLOW: BC_assign_INFLOW(par, grid, b); break;
         case REFLECTING: BC_assign_REFLECTING(par, grid, b); break;
         case AXISYMMETRIC: BC_assign_AXISYMMETRIC(par, grid, b); break;
+        case JETREFLECT: BC_assign_JETREFLECT(par, grid, b); break;
         case FIXED: BC_assign_FIXED(par, grid, b); break;
         case DMACH: BC_assign_DMACH(par, grid, b); break;
         case DMACH2:
@@ -550,6 +554,7 @@ struct RefSim : public periodic_bc,
         case INFLOW: BC_update_INFLOW(par, grid, b, cstep, maxstep); break;
         case REFLECTING: BC_update_REFLECTING(par, grid, b, cstep, maxstep); break;
         case AXISYMMETRIC: BC_update_AXISYMMETRIC(par, grid, b, cstep, maxstep); break;
+        case JETREFLECT: BC_update_JETREFLECT(par, grid, b, cstep, maxstep); break;
         case FIXED: BC_update_FIXED(par, grid, b, cstep, maxstep); break;
         case DMACH: BC_update_DMACH(par, grid, simtime, b, cstep, maxstep); break;
         case DMACH2: BC_update_DMACH2(par, grid, b, cstep, maxstep); break;

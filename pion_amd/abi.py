@@ -18,11 +18,11 @@ FLUX_RSroe_pv, FLUX_FVS, FLUX_RS_HLLD, FLUX_RS_HLL = 5, 6, 7, 8
 AV_NONE, AV_FKJ98_1D, AV_HCORRECTION, AV_HCORR_FKJ98 = 0, 1, 3, 4
 # boundaries
 BC_NONE, BC_PERIODIC, BC_OUTFLOW, BC_INFLOW, BC_REFLECTING, BC_FIXED = 0, 1, 2, 3, 4, 5
-BC_ONEWAY_OUT, BC_DMACH, BC_DMACH2, BC_STWIND, BC_SLAB, BC_JET, BC_AXISYMMETRIC = 6, 7, 8, 9, 10, 11, 12
+BC_ONEWAY_OUT, BC_DMACH, BC_DMACH2, BC_STWIND, BC_SLAB, BC_JET, BC_AXISYMMETRIC, BC_JETREFLECT = 6, 7, 8, 9, 10, 11, 12, 13
 BC_NAMES = {
     "periodic": BC_PERIODIC, "outflow": BC_OUTFLOW, "inflow": BC_INFLOW,
     "reflecting": BC_REFLECTING, "fixed": BC_FIXED, "one-way-outflow": BC_ONEWAY_OUT,
-    "DMR": BC_DMACH, "slab": BC_SLAB, "axisymmetric": BC_AXISYMMETRIC,
+    "DMR": BC_DMACH, "slab": BC_SLAB, "axisymmetric": BC_AXISYMMETRIC, "jetreflect": BC_JETREFLECT,
 }
 COOL_NONE, COOL_WSS09_CIE_LINE_HEAT_COOL = 0, 8
 # cell flags

@@ -125,10 +125,11 @@ __global__ __launch_bounds__(256) void k_bc_face(const BCArgs a)
     case PION_BC_OUTFLOW:
     case PION_BC_ONEWAY_OUT:
     case PION_BC_AXISYMMETRIC:
+    case PION_BC_JETREFLECT:
     case PION_BC_REFLECTING: {
       // all ghost layers copy the FIRST on-grid cell of the row (outflow_boundaries.cpp:50-59)
       const long s = pos ? c - st * depth : c + st * depth;
-      if (a.type == PION_BC_REFLECTING || a.type == PION_BC_AXISYMMETRIC) {
+      if (a.type == PION_BC_REFLECTING || a.type == PION_BC_AXISYMMETRIC || a.type == PION_BC_JETREFLECT) {
         // reflecting_boundaries.cpp:34-73,131-153: normal velocity (and normal B) flip sign;
         // axisymmetric_boundaries.cpp:34-52,98-137 (R = 0 axis): the radial and the theta components do
         const bool mhd = (a.eqntype == EQMHD || a.eqntype == EQGLM);
@@ -138,6 +139,11 @@ __global__ __launch_bounds__(256) void k_bc_face(const BCArgs a)
           if (axi) {
             if (v == 3 || v == 4) r = -1.0;
             if (mhd && (v == 6 || v == 7)) r = -1.0;
+          }
+          else if (a.type == PION_BC_JETREFLECT) {
+            // jetreflect_boundaries.cpp:32-62: v_n and the two tangential field components
+            if (v == 2 + ax) r = -1.0;
+            if (mhd && v >= 5 && v <= 7 && v != 5 + ax) r = -1.0;
           }
           else {
             if (v == 2 + ax) r = -1.0;

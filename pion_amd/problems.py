@@ -179,18 +179,19 @@ def jet3d(n, solver=abi.FLUX_RSroe, jetradius=3, strict_fp=0):
     return cfg, P, (jetradius, jetstate)
 
 
-def jet_axi2d(n, eqntype=abi.EQGLM, solver=abi.FLUX_RS_HLLD, jetradius=4, strict_fp=0):
+def jet_axi2d(n, eqntype=abi.EQGLM, solver=abi.FLUX_RS_HLLD, jetradius=4, strict_fp=0, xn="outflow"):
     """2-D axisymmetric (z,R) magnetised jet (ics/jet.cpp, boundaries/jet_boundaries.cpp 2-D branch): uniform
     ambient medium with an axial field, axisymmetric BC on the axis, outflow elsewhere, internal JETBC on XN."""
     nvb = {abi.EQEUL: 5, abi.EQMHD: 8, abi.EQGLM: 9}[eqntype]
     ref = [1.0, 1.0, 1.0, 1.0, 1.0] + ([1.0, 1.0, 1.0] if nvb >= 8 else []) + ([1.0] if nvb == 9 else []) + [1.0]
     cfg = abi.make_config(2, [n, n // 2], eqntype, solver, ntracer=1, artvisc=abi.AV_FKJ98_1D, etav=0.15,
                           gamma=5.0 / 3.0, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(1.0, 0.5, 0.0),
-                          bcs=["outflow", "outflow", "axisymmetric", "outflow"], refvec=ref, strict_fp=strict_fp,
+                          bcs=[xn, "outflow", "axisymmetric", "outflow"], refvec=ref, strict_fp=strict_fp,
                           coord_sys=2)
     P = alloc(cfg)
+    X, Y, Z = mesh(cfg)
     P[abi.RO] = 1.0
-    P[abi.PG] = 1.0
+    P[abi.PG] = 1.0 + 2.0 * np.exp(-((X - 0.2) ** 2 + Y * Y) / 0.01)   # a pressure bump near the XN wall
     js = np.zeros(cfg.nvar)
     js[abi.RO], js[abi.PG], js[abi.VX] = 0.5, 1.0, 2.0
     if nvb >= 8:

@@ -81,7 +81,7 @@ STEP_CASES = ["hd_roe_3d", "hd_fvs_2d_tr", "hd_roe_hcorr_2d", "hd_hll_1d", "mhd_
 
 STEP_CASES_B = ["mhd_roe_hcorr_2d", "glm_roe_3d", "glm_linear_2d", "hd_jet_3d",
                 "cyl_hd_roe", "cyl_hd_hcorr_tr", "cyl_mhd_hlld", "cyl_glm_hlld", "cyl_glm_roe_oa1",
-                "sph_hd_roe_tr", "sph_hd_hcorr", "sph_hd_hybrid_oa1", "cyl_glm_jet"]   # steps_b.npz (added with flux_kat_b.npz)
+                "sph_hd_roe_tr", "sph_hd_hcorr", "sph_hd_hybrid_oa1", "cyl_glm_jet", "cyl_glm_jetreflect"]   # steps_b.npz (added with flux_kat_b.npz)
 
 
 def step_setup(name, sim):
@@ -89,7 +89,7 @@ def step_setup(name, sim):
     if name == "hd_jet_3d":
         _, _, (radius, state) = problems.jet3d(12)
         sim.set_jet(radius, state)
-    if name == "cyl_glm_jet":
+    if name in ("cyl_glm_jet", "cyl_glm_jetreflect"):
         _, _, (radius, state) = problems.jet_axi2d(24)
         sim.set_jet(radius, state)
 
@@ -108,6 +108,9 @@ def step_case(name, strict_fp=1):
         return cfg, P
     if name == "cyl_glm_jet":
         cfg, P, _ = problems.jet_axi2d(24, strict_fp=strict_fp)
+        return cfg, P
+    if name == "cyl_glm_jetreflect":
+        cfg, P, _ = problems.jet_axi2d(24, strict_fp=strict_fp, xn="jetreflect")
         return cfg, P
     if name == "cyl_hd_roe":
         return problems.blast_axi2d(24, abi.EQEUL, abi.FLUX_RSroe, strict_fp=strict_fp)
