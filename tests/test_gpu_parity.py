@@ -271,3 +271,32 @@ def test_hd_roe_with_hcorrection_instances_3d(ntr, strict, monkeypatch):
         run_pair(cfg, P, 2)
     else:
         _fast_rows_vs_cell(cfg, P, 2, monkeypatch)
+
+
+def test_conserved_totals_fast_build_vs_cpu():
+    """BASELINE gate: sums of the conserved quantities of the production (fast) build within 1e-10
+    (relative to the sum of magnitudes) of the CPU reference path after several steps"""
+    cfg, P = problems.mhd_blastwave(48, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=0)
+    g_ = cfg.gamma
+
+    def totals(A):
+        q = A[:, 2:-2, 2:-2, 2:-2]
+        ro, pg, v, B = q[0], q[1], q[2:5], q[5:8]
+        E = pg / (g_ - 1.0) + 0.5 * ro * (v ** 2).sum(axis=0) + 0.5 * (B ** 2).sum(axis=0)
+        vals = [ro, ro * v[0], ro * v[1], ro * v[2], E, B[0], B[1], B[2]]
+        return np.array([x.sum() for x in vals]), np.array([np.abs(x).sum() for x in vals])
+
+    with _gpu(cfg) as g, _cpu(cfg) as o:
+        sg, so = driver.SimControl(g, cfg), driver.SimControl(o, cfg)
+        sg.init(P)
+        so.init(P)
+        for _ in range(8):
+            sg.calculate_timestep()
+            so.calculate_timestep()
+            so.dt = sg.dt
+            sg.advance_time()
+            so.advance_time()
+        tg, ag = totals(g.download(0))
+        to, _ = totals(o.download(0))
+    rel = np.abs(tg - to) / (ag + 1e-300)
+    assert rel.max() <= 1e-10, rel
