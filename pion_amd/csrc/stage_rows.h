@@ -3,17 +3,21 @@
 // Included by kernels_fp.hip inside namespace pion::PION_FPNS (after stage_march.h, whose helpers
 // load_rot / slope3 / apply_axis / cell_update_store it reuses).
 //
-// Same dataflow as k_stage_march (one wavefront per x-pencil of 64 cells, 62 outputs, marching
-// along z, x fluxes shared by wavefront shuffles) with two changes aimed at what the profile of
-// k_stage_march showed (fp64 VALU-bound, 4 Riemann solves per cell, 1 wave/SIMD, 28 % of the wave
-// time parked on memory):
+// Same dataflow as k_stage_march (one wavefront per x-pencil of 64 lanes, marching along z, x fluxes
+// shared by wavefront shuffles) with what the profiles asked for:
 //   * a wavefront owns R consecutive y-rows and visits them one after the other inside each
 //     z-plane, carrying the flux through the upper y face (and the slope of the next row) to the
-//     next row in registers: (3R+1)/R Riemann solves and (3R+2)/R.. slopes per cell instead of 4 / 5;
+//     next row in registers: (3R+1)/R Riemann solves per cell instead of 4;
 //   * the z-carried state (slope of the current plane, flux through the lower z face) of every
-//     row lives in LDS ([row][var][lane], conflict-free 8-byte accesses), not in registers, so the
-//     kernel fits 256 VGPRs and two wavefronts share a SIMD to cover memory latency.
-// The arithmetic and its order are unchanged (strict build stays bit-identical to the oracle).
+//     row lives in LDS ([row][var][lane], conflict-free 8-byte accesses), not in registers;
+//   * loads are ordered for the one wavefront a SIMD holds (in-order return): what a task needs at
+//     once first, then the rows that come from HBM, requested a Riemann solve ahead of their use;
+//   * the remainder of a row that does not fill a 62-cell tile shares a wavefront with the
+//     remainders of the next row groups (RowsTiling);
+//   * the production instances are specialised at compile time (OAMODE, PLAIN; stage_rows_go);
+//   * on a second-order full step the kernel leaves the next time step's minima behind (dtres).
+// It still runs one wavefront per SIMD (256 VGPR + AGPRs).  The arithmetic and its order are the
+// reference's (the strict build stays bit-identical to the oracle).
 #ifndef PION_STAGE_ROWS_H
 #define PION_STAGE_ROWS_H
 
