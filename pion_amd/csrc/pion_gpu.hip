@@ -367,6 +367,15 @@ int check_errword(Handle *h)
   return 0;
 }
 
+// device scratch of the test seams: freed on every return path
+struct DevBuf {
+  double *p = nullptr;
+  ~DevBuf()
+  {
+    if (p) (void)hipFree(p);
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -1172,13 +1181,14 @@ int pion_gpu_interface_flux(void *handle, int n, int axis, double dt, const doub
 {
   Handle *h = use(handle);
   const int nv = h->cfg.nvar;
-  double *dl, *dr, *da, *df, *dp;
+  DevBuf bl, br, ba, bf, bp;
   const size_t nb = sizeof(double) * (size_t)n * nv;
-  HCHECK(h, hipMalloc(&dl, nb));
-  HCHECK(h, hipMalloc(&dr, nb));
-  HCHECK(h, hipMalloc(&df, nb));
-  HCHECK(h, hipMalloc(&dp, nb));
-  HCHECK(h, hipMalloc(&da, sizeof(double) * 4 * n));
+  HCHECK(h, hipMalloc(&bl.p, nb));
+  HCHECK(h, hipMalloc(&br.p, nb));
+  HCHECK(h, hipMalloc(&bf.p, nb));
+  HCHECK(h, hipMalloc(&bp.p, nb));
+  HCHECK(h, hipMalloc(&ba.p, sizeof(double) * 4 * n));
+  double *dl = bl.p, *dr = br.p, *da = ba.p, *df = bf.p, *dp = bp.p;
   HCHECK(h, hipMemcpy(dl, Pl, nb, hipMemcpyHostToDevice));
   HCHECK(h, hipMemcpy(dr, Pr, nb, hipMemcpyHostToDevice));
   HCHECK(h, hipMemcpy(da, aux, sizeof(double) * 4 * n, hipMemcpyHostToDevice));
@@ -1196,20 +1206,13 @@ int pion_gpu_interface_flux(void *handle, int n, int axis, double dt, const doub
   a.errword = h->derr;
   a.fc = make_fluxctx(h, dt);
   int rc = h->cfg.strict_fp ? fp_strict::launch_flux_test(a, h->stream) : fp_fast::launch_flux_test(a, h->stream);
-  if (rc == 0) {
-    HCHECK(h, hipStreamSynchronize(h->stream));
-    HCHECK(h, hipMemcpy(F, df, nb, hipMemcpyDeviceToHost));
-    HCHECK(h, hipMemcpy(Pstar, dp, nb, hipMemcpyDeviceToHost));
-  }
-  hipFree(dl);
-  hipFree(dr);
-  hipFree(da);
-  hipFree(df);
-  hipFree(dp);
   if (rc != 0) {
     h->err = "interface-flux launch failed";
     return PION_GPU_EDEVICE;
   }
+  HCHECK(h, hipStreamSynchronize(h->stream));
+  HCHECK(h, hipMemcpy(F, df, nb, hipMemcpyDeviceToHost));
+  HCHECK(h, hipMemcpy(Pstar, dp, nb, hipMemcpyDeviceToHost));
   // the physics error word is informational here (tests feed extreme states)
   int z = 0;
   hipMemcpy(h->derr, &z, sizeof(int), hipMemcpyHostToDevice);
@@ -1231,7 +1234,8 @@ static int cool_go(Handle *h, int n, double dt, const double *Pin, double *Pout,
   a.gamma = h->cfg.gamma;
   a.errword = h->derr;
   a.cool = h->cool;
-  double *d0 = nullptr, *d1 = nullptr, *d2 = nullptr;
+  DevBuf b0, b1, b2;
+  double *&d0 = b0.p, *&d1 = b1.p, *&d2 = b2.p;
   int rc;
   if (Pin) {
     const size_t nb = sizeof(double) * (size_t)n * a.nvar;
@@ -1258,9 +1262,6 @@ static int cool_go(Handle *h, int n, double dt, const double *Pin, double *Pout,
     HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, hipMemcpy(edot, d2, nb, hipMemcpyDeviceToHost));
   }
-  hipFree(d0);
-  hipFree(d1);
-  hipFree(d2);
   if (rc != 0) return PION_GPU_EDEVICE;
   return check_errword(h);
 }
