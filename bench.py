@@ -195,6 +195,18 @@ def main():
                 and os.path.exists(tfile)):
             with open(tfile) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
+        # where the time goes, from the committed SQ counter pass of this command (the kernel is fp64-VALU
+        # and latency bound, not HBM bound): instructions per launch, share of wave cycles issuing VALU /
+        # parked on s_waitcnt
+        valu = None
+        sfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_sq_stage_kernel.json")
+        if traffic is not None and os.path.exists(sfile):
+            with open(sfile) as f:
+                c = json.load(f)["counters"]
+            valu = {"valu_insts_per_launch": c["SQ_INSTS_VALU"],
+                    "valu_active_frac_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                    "waitcnt_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                    "source": "profiles/r01_pmc_sq_stage_kernel.json"}
         out = {
             "metric": "Mcell-updates/s on 3D ideal-MHD 512^3 uniform grid; achieved HBM GB/s vs peak",
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
@@ -211,7 +223,7 @@ def main():
                          "kernel": {"m1": "k_stage_rows<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows<MHD,0,HLLD>",
                                     "m2": "k_stage_rows<EUL,0,Roe-CV>", "m3": "k_stage_rows<EUL,1,FVS>"}[args.workload],
                          "kernel_ms": stage_ms, "launches_per_stage": tm["stage_n"] / (2.0 * args.steps), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
-                         "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes},
+                         "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes, "issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "m1":
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, eq, solver)

@@ -10,7 +10,13 @@ for f in glob.glob("$OUT/pmc_sq_$1/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "k_stage_rows" in r["Kernel_Name"]:
             acc[r["Counter_Name"]][r["Dispatch_Id"]].append(float(r["Counter_Value"]))
+import json
+out = {}
 for k, d in sorted(acc.items()):
     vals = [sum(v) for v in d.values()]
-    print("$1", k, "%.4g" % (sum(vals) / len(vals)), "n=%d" % len(vals))
+    out[k] = sum(vals) / len(vals)
+    print("$1", k, "%.4g" % out[k], "n=%d" % len(vals))
+json.dump({"what": "SQ counters per k_stage_rows launch (mean of the first- and second-order stage instances), "
+                   "bench.py --steps 2 --warmup 1 --grid ${2:-512}, rocprofv3 --pmc (one pass, with --kernel-trace only)",
+           "counters": out}, open("$OUT/pmc_sq_$1.json", "w"), indent=1)
 PY
