@@ -171,10 +171,18 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
       double P0[NV], yfar[NV], zfar[NV];
       uint8_t fl = 0;
       const long far = oa2 ? 2 : 1;
+      // LATE_P0 (second-order plain instances): the registers of P0 first carry the +1 z plane, requested
+      // here and consumed when the z task builds its states; the start-of-step state is then requested
+      // into the same registers just before the z solve and used after it.  Both are one solve ahead of
+      // their use, for the price of one array.
+      constexpr bool LATE_P0 = (OAMODE == 2 && PLAIN && NTR == 0);   // (with tracers the extra live range spills)
+      if (LATE_P0) load_rot<NV, MHD>(a.S, nc, 2, c + sz, P0);
       if (!prime) {
+        if (!LATE_P0) {
 #pragma unroll
-        for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
-        fl = a.flags[c];
+          for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
+          fl = a.flags[c];
+        }
         load_rot<NV, MHD>(a.S, nc, 1, c + far * sy, yfar);
       }
       load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
@@ -328,7 +336,11 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           double zq0[NV], qp1[NV], qp2[NV], sn[NV];
           to_sweep<NV, MHD>(2, q0, zq0);
           if (oa2) {
-            load_rot<NV, MHD>(a.S, nc, 2, c + sz, qp1);
+            if (LATE_P0) {
+#pragma unroll
+              for (int v = 0; v < NV; v++) qp1[v] = P0[v];   // the +1 plane requested at the row start
+            }
+            else load_rot<NV, MHD>(a.S, nc, 2, c + sz, qp1);
 #pragma unroll
             for (int v = 0; v < NV; v++) qp2[v] = zfar[v];
           }
@@ -371,6 +383,11 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           else if (t == 1) use_hll = (a.hllflag[cl] | (hf & 1u)) != 0;
           else if (t == 2) use_hll = (hf & 5u) != 0;
           else use_hll = (hf & 9u) != 0;
+        }
+        if (LATE_P0 && t == 3 && !prime) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
+          fl = a.flags[c];
         }
         FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 
