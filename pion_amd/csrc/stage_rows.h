@@ -165,6 +165,17 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           xqp[v] = a.S[v * nc + c + 1];
         }
       }
+      // HLLD -> HLL switch flags of this cell and its three upper neighbours: the x task needs two of
+      // them at once, so they are requested BEFORE the HBM-bound prefetches below (in-order return)
+      uint8_t hf0 = 0, hfx = 0, hfy = 0, hfz = 0;
+      if constexpr (MHD && SOLVER == FLUX_RS_HLLD && PLAIN) {
+        hf0 = a.hllflag[c];
+        if (!prime) {
+          hfx = a.hllflag[c + 1];
+          hfy = a.hllflag[c + sy];
+        }
+        hfz = a.hllflag[c + sz];
+      }
       double dU[NV];
 #pragma unroll
       for (int v = 0; v < NV; v++) dU[v] = 0.0;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
       // small values the y and z tasks would otherwise fetch right before their solve (a dependent
       // L2 round trip each): B_n / psi of the lower neighbours and the HLLD -> HLL switch flags
       double ybnm = 0.0, ysim = 0.0, zbnm = 0.0, zsim = 0.0;
-      unsigned hf = 0;   // bit 0: this cell, 1: +x, 2: +y, 3: +z
+      unsigned hf = 0;   // bit 0: this cell, 1: +x, 2: +y, 3: +z  (non-plain instances)
       if constexpr (MHD) {
         zbnm = a.S[(long)rotvar<MHD>(2, qBN) * nc + c - sz];
         if constexpr (EQ == EQGLM) zsim = a.S[(long)qSI * nc + c - sz];
@@ -197,7 +208,10 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           ybnm = a.S[(long)rotvar<MHD>(1, qBN) * nc + c - sy];
           if constexpr (EQ == EQGLM) ysim = a.S[(long)qSI * nc + c - sy];
         }
-        if constexpr (SOLVER == FLUX_RS_HLLD) {
+        if constexpr (SOLVER == FLUX_RS_HLLD && !PLAIN) {
+          // (the instances with H-correction / microphysics keep the flags here, packed, after the
+          // prefetches: with the early placement the fast GLM + H-correction instances came out wrong --
+          // one more entry for the Makefile's list)
           hf = (unsigned)a.hllflag[c] | ((unsigned)a.hllflag[c + sz] << 3);
           if (!prime) hf |= ((unsigned)a.hllflag[c + 1] << 1) | ((unsigned)a.hllflag[c + sy] << 2);
         }
@@ -379,10 +393,18 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
         bool use_hll = false;
         if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-          if (t == 0) use_hll = (hf & 3u) != 0;
-          else if (t == 1) use_hll = (a.hllflag[cl] | (hf & 1u)) != 0;
-          else if (t == 2) use_hll = (hf & 5u) != 0;
-          else use_hll = (hf & 9u) != 0;
+          if constexpr (PLAIN) {
+            if (t == 0) use_hll = (hf0 | hfx) != 0;
+            else if (t == 1) use_hll = (a.hllflag[cl] | hf0) != 0;
+            else if (t == 2) use_hll = (hf0 | hfy) != 0;
+            else use_hll = (hf0 | hfz) != 0;
+          }
+          else {
+            if (t == 0) use_hll = (hf & 3u) != 0;
+            else if (t == 1) use_hll = (a.hllflag[cl] | (hf & 1u)) != 0;
+            else if (t == 2) use_hll = (hf & 5u) != 0;
+            else use_hll = (hf & 9u) != 0;
+          }
         }
         if (LATE_P0 && t == 3 && !prime) {
 #pragma unroll
