@@ -197,6 +197,12 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         load_rot<NV, MHD>(a.S, nc, 1, c + far * sy, yfar);
       }
       load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
+      if (!prime && r == 0) {
+        // first row of the group: the two rows below it (the lower y task) land in the registers of the
+        // y carry, which holds nothing until that task has run
+        load_rot<NV, MHD>(a.S, nc, 1, c - sy, Fy);
+        if (oa2) load_rot<NV, MHD>(a.S, nc, 1, c - 2 * sy, ysn);
+      }
       // small values the y and z tasks would otherwise fetch right before their solve (a dependent
       // L2 round trip each): B_n / psi of the lower neighbours and the HLLD -> HLL switch flags
       double ybnm = 0.0, ysim = 0.0, zbnm = 0.0, zsim = 0.0;
@@ -275,14 +281,13 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           st = sy;
           cl = c - sy;
           double qm2[NV], qm1[NV], qp1[NV], yq0[NV], sm1[NV];
-          load_rot<NV, MHD>(a.S, nc, 1, c - sy, qm1);
+#pragma unroll
+          for (int v = 0; v < NV; v++) {
+            qm1[v] = Fy[v];                   // requested at the row start
+            qm2[v] = oa2 ? ysn[v] : 0.0;
+          }
           load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
           to_sweep<NV, MHD>(1, q0, yq0);
-          if (oa2) load_rot<NV, MHD>(a.S, nc, 1, c - 2 * sy, qm2);
-          else {
-#pragma unroll
-            for (int v = 0; v < NV; v++) qm2[v] = 0.0;
-          }
           slope3<NV>(qm2, qm1, yq0, dx, oa2, sm1);
           slope3<NV>(qm1, yq0, qp1, dx, oa2, ys0);
 #pragma unroll
