@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
       double dU[NV];
 #pragma unroll
       for (int v = 0; v < NV; v++) dU[v] = 0.0;
-      double P0[NV], yfar[NV], zfar[NV];
+      double P0[NV], yfar[NV], zfar[NV], ynear[NV];
+      // second-order plain instances also request the +1 y row here (register headroom permitting)
+      constexpr bool YNEAR_PRE = (OAMODE == 2 && PLAIN && NTR == 0);
       uint8_t fl = 0;
       const long far = oa2 ? 2 : 1;
       // LATE_P0 (second-order plain instances): the registers of P0 first carry the +1 z plane, requested
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           fl = a.flags[c];
         }
         load_rot<NV, MHD>(a.S, nc, 1, c + far * sy, yfar);
+        if (YNEAR_PRE) load_rot<NV, MHD>(a.S, nc, 1, c + sy, ynear);
       }
       load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
       if (!prime && r == 0) {
@@ -286,7 +289,11 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
             qm1[v] = Fy[v];                   // requested at the row start
             qm2[v] = oa2 ? ysn[v] : 0.0;
           }
-          load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
+          if (YNEAR_PRE) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp1[v] = ynear[v];
+          }
+          else load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
           to_sweep<NV, MHD>(1, q0, yq0);
           slope3<NV>(qm2, qm1, yq0, dx, oa2, sm1);
           slope3<NV>(qm1, yq0, qp1, dx, oa2, ys0);
@@ -310,7 +317,11 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
           double yq0[NV], qp1[NV], qp2[NV], sp[NV];
           to_sweep<NV, MHD>(1, q0, yq0);
           if (oa2) {
-            load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
+            if (YNEAR_PRE) {
+#pragma unroll
+              for (int v = 0; v < NV; v++) qp1[v] = ynear[v];
+            }
+            else load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
 #pragma unroll
             for (int v = 0; v < NV; v++) qp2[v] = yfar[v];
           }
