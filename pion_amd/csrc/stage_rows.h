@@ -167,12 +167,13 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
       }
       // HLLD -> HLL switch flags of this cell and its three upper neighbours: the x task needs two of
       // them at once, so they are requested BEFORE the HBM-bound prefetches below (in-order return)
-      uint8_t hf0 = 0, hfx = 0, hfy = 0, hfz = 0;
+      uint8_t hf0 = 0, hfx = 0, hfy = 0, hfz = 0, hfm = 0;
       if constexpr (MHD && SOLVER == FLUX_RS_HLLD && PLAIN) {
         hf0 = a.hllflag[c];
         if (!prime) {
           hfx = a.hllflag[c + 1];
           hfy = a.hllflag[c + sy];
+          if (r == 0) hfm = a.hllflag[c - sy];   // lower y face of the group's first row
         }
         hfz = a.hllflag[c + sz];
       }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
         if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
           if constexpr (PLAIN) {
             if (t == 0) use_hll = (hf0 | hfx) != 0;
-            else if (t == 1) use_hll = (a.hllflag[cl] | hf0) != 0;
+            else if (t == 1) use_hll = (hfm | hf0) != 0;
             else if (t == 2) use_hll = (hf0 | hfy) != 0;
             else use_hll = (hf0 | hfz) != 0;
           }
