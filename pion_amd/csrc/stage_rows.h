@@ -271,11 +271,23 @@ __global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageAr
             eR[v] = __shfl_down(em, 1, 64);
           }
           if constexpr (MHD) {
-            bnm = qm[qBN];
-            bnp = qp[qBN];
-            if constexpr (EQ == EQGLM) {
-              sim = qm[qSI];
-              sip = qp[qSI];
+            if (OAMODE == 1) {
+              // first order: the x neighbours are only needed for B_n and psi, and those are the
+              // neighbouring lanes' own cell values (the end lanes are halo lanes, their result is unused)
+              bnm = __shfl_up(q0[qBN], 1, 64);
+              bnp = __shfl_down(q0[qBN], 1, 64);
+              if constexpr (EQ == EQGLM) {
+                sim = __shfl_up(q0[qSI], 1, 64);
+                sip = __shfl_down(q0[qSI], 1, 64);
+              }
+            }
+            else {
+              bnm = qm[qBN];
+              bnp = qp[qBN];
+              if constexpr (EQ == EQGLM) {
+                sim = qm[qSI];
+                sip = qp[qSI];
+              }
             }
           }
         }
