@@ -94,8 +94,8 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=64)
     ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3"],
                     help="m1 (default, the headline): MHD blast; m2: 3-D Euler Roe-CV octant Sedov blast (SURVEY 8d); "
-                         "m3: Wind3D single level, FVS + cooling 8 + stellar wind.  m2/m3 are extra rows for "
-                         "DESIGN.md, single GPU only")
+                         "m3: Wind3D single level, FVS + cooling 8 + stellar wind (single GPU).  m2/m3 are extra rows for "
+                         "DESIGN.md")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
                          "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
@@ -127,6 +127,7 @@ def main():
     n = args.n
     wl_name = None
     dt_lim = None
+    periodic_z = True
     if args.workload == "m1":
         cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
         cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
@@ -134,14 +135,22 @@ def main():
         cfg = slab.slab_config(cfg_g, rank, world)
         P = problems.fill_mhd_blastwave(cfg)
         sim = lib.GpuSim(cfg, local_rank)
+    elif args.workload == "m2":
+        # BASELINE configs[3]: 3-D HD blast 512^3, z-slabs over the GPUs (physical z faces on the end ranks)
+        cfg_g, _ = problems.hd_blast_octant(4, 3, solver=abi.FLUX_RSroe, strict_fp=args.strict)   # template
+        L = cfg_g.dx * 4
+        cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
+        cfg_g.dx = L / n
+        cfg = slab.slab_config(cfg_g, rank, world)
+        P = problems.fill_hd_blast_octant(cfg, n / 32.0)
+        wl_name = "M2: 3-D Euler octant Sedov blast %d^3, Roe-CV + FKJ98 0.1, reflecting/outflow, OA2/OA2" % n
+        periodic_z = False
+        sim = lib.GpuSim(cfg, local_rank)
+        eq = cfg.eqntype
     else:
         if world != 1:
-            raise SystemExit("--workload m2/m3: single GPU only")
-        if args.workload == "m2":
-            cfg, P = problems.hd_blast_octant(n, 3, solver=abi.FLUX_RSroe, strict_fp=args.strict, nzones=n / 32.0)
-            wl_name = "M2: 3-D Euler octant Sedov blast %d^3, Roe-CV + FKJ98 0.1, reflecting/outflow, OA2/OA2" % n
-            sim = lib.GpuSim(cfg, local_rank)
-        else:
+            raise SystemExit("--workload m3: single GPU only")
+        if True:
             from pion_amd import cooling
             cfg, P, (widx, wst), dt_lim = problems.wind3d(n, strict_fp=args.strict)
             wl_name = ("M3: Wind3D single level %d^3, Euler + tracer, FVS + FKJ98 0.15, cooling 8, stellar wind, "
@@ -151,7 +160,7 @@ def main():
             sim.set_wind_cells(widx, wst)
         eq = cfg.eqntype
     if world > 1:
-        comm = slab.SlabComm(rank, world, True, sim.halo_count(), torch.device("cuda", local_rank))
+        comm = slab.SlabComm(rank, world, periodic_z, sim.halo_count(), torch.device("cuda", local_rank))
         comm.use_streams(sim)   # exchange under the interior part of each stage, no host waits
     sc = driver.SimControl(sim, cfg, comm=comm)
     sc.first_step_dt_limit = dt_lim

@@ -102,18 +102,26 @@ def hd_blast_octant(n, ndim=3, solver=abi.FLUX_RSroe, ntracer=0, artvisc=abi.AV_
     cfg = abi.make_config(ndim, ng, abi.EQEUL, solver, ntracer=ntracer, artvisc=artvisc, etav=0.1,
                           gamma=5.0 / 3.0, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(L, L, L), bcs=bcs,
                           refvec=[rho0, p0, 1e6, 1e6, 1e6] + [1.0] * ntracer, strict_fp=strict_fp)
+    return cfg, fill_hd_blast_octant(cfg, nzones)
+
+
+def fill_hd_blast_octant(cfg, nzones):
+    """IC of hd_blast_octant for any (global or slab) configuration, built plane-wise."""
+    rho0, p0 = 2.338e-24, 1.38e-13
     P = alloc(cfg)
-    X, Y, Z = mesh(cfg)
-    r2 = X * X + (Y * Y if ndim > 1 else 0.0) + (Z * Z if ndim > 2 else 0.0)
+    x, y, z = cell_centres(cfg)
     rb = nzones * cfg.dx
-    P[abi.RO] = rho0
-    # 1e51 erg in the full sphere
-    vol = 4.0 / 3.0 * math.pi * rb ** 3
+    vol = 4.0 / 3.0 * math.pi * rb ** 3        # 1e51 erg in the full sphere
     pin = 1.0e51 * (cfg.gamma - 1.0) / vol
-    P[abi.PG] = np.where(r2 < rb * rb, pin, p0)
-    for t in range(ntracer):
-        P[5 + t] = np.where(r2 < rb * rb, 1.0, 0.0)
-    return cfg, P
+    P[abi.RO] = rho0
+    xy2 = x[None, :] ** 2 + (y[:, None] ** 2 if cfg.ndim > 1 else 0.0)
+    for k in range(z.size):
+        r2 = xy2 + (z[k] ** 2 if cfg.ndim > 2 else 0.0)
+        hot = r2 < rb * rb
+        P[abi.PG, k] = np.where(hot, pin, p0)
+        for t in range(cfg.ntracer):
+            P[5 + t, k] = np.where(hot, 1.0, 0.0)
+    return P
 
 
 def blast_axi2d(n, eqntype=abi.EQEUL, solver=abi.FLUX_RSroe, ntracer=0, artvisc=abi.AV_FKJ98_1D, strict_fp=0):
