@@ -148,16 +148,21 @@ def main():
         sim = lib.GpuSim(cfg, local_rank)
         eq = cfg.eqntype
     else:
-        if world != 1:
-            raise SystemExit("--workload m3: single GPU only")
-        if True:
-            from pion_amd import cooling
-            cfg, P, (widx, wst), dt_lim = problems.wind3d(n, strict_fp=args.strict)
-            wl_name = ("M3: Wind3D single level %d^3, Euler + tracer, FVS + FKJ98 0.15, cooling 8, stellar wind, "
-                       "reflecting/one-way, OA2/OA2" % n)
-            sim = lib.GpuSim(cfg, local_rank)
-            sim.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
-            sim.set_wind_cells(widx, wst)
+        # BASELINE configs[4]: Wind3D with the cooling source term, z-slabs over the GPUs
+        from pion_amd import cooling
+        cfg_g, _, _, _ = problems.wind3d(8, strict_fp=args.strict)   # template
+        L = cfg_g.dx * 8
+        cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
+        cfg_g.dx = L / n
+        cfg = slab.slab_config(cfg_g, rank, world)
+        P, (widx, wst), dt_lim = problems.fill_wind3d(cfg, n)
+        wl_name = ("M3: Wind3D single level %d^3, Euler + tracer, FVS + FKJ98 0.15, cooling 8, stellar wind, "
+                   "reflecting/one-way, OA2/OA2" % n)
+        periodic_z = False
+        sim = lib.GpuSim(cfg, local_rank)
+        sim.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
+        if widx.size:
+            sim.set_wind_cells(widx, wst)   # (ranks away from the source hold no wind cell)
         eq = cfg.eqntype
     if world > 1:
         comm = slab.SlabComm(rank, world, periodic_z, sim.halo_count(), torch.device("cuda", local_rank))

@@ -278,16 +278,23 @@ def wind3d(n, strict_fp=0):
                           gamma=1.6666666666666667, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(L, L, L), bcs=bcs,
                           refvec=[1.0e-24, 1.0e-13, 1.0e6, 1.0e6, 1.0e6, 1.0], min_temp=5.0e3, max_temp=1.0e8,
                           cooling=abi.COOL_WSS09_CIE_LINE_HEAT_COOL, mp_timestep_limit=1, strict_fp=strict_fp)
+    P, (idx, st), dt_lim = fill_wind3d(cfg, n)
+    return cfg, P, (idx, st), dt_lim
+
+
+def fill_wind3d(cfg, n_global):
+    """IC, wind cells and first-step dt limit of wind3d for any (global or slab) configuration"""
     P = alloc(cfg)
     P[abi.RO] = 2.124229813e-24
     P[abi.PG] = 2.209037632e-12
     # keep the wind region resolved like the shipped set-up (12 cells at 128^3 on the finest of 2 levels)
+    n = n_global
     radius = 1.543e17 * max(1.0, 256.0 / n) if n < 256 else 1.543e17
     idx, st = wind_cells(cfg, (0.0, 0.0, 0.0), radius, 1.0e-7, 1500.0, 3.0e4, 6.96e11, [1.0])
     for v in range(cfg.nvar):
         P[v].reshape(-1)[idx] = st[:, v]
     dt_lim = 0.1 * cfg.cfl * cfg.dx / (1500.0 * 1.0e5)   # calc_timestep.cpp:319-323
-    return cfg, P, (idx, st), dt_lim
+    return P, (idx, st), dt_lim
 
 
 def random_states(rng, n, eqntype, ntracer=0, kind="mixed"):
