@@ -30,6 +30,7 @@ def _worker(rank, world, port, case, nsteps, q):
         assert comm.host_staged
         comm.use_streams(g)
         sc = driver.SimControl(g, cfg, comm=comm)
+        sc.first_step_dt_limit = _setup(case, g, cfg)
         sc.init(slab.slab_slice(P, cfg_g, rank, world))
         sc.time_int(nsteps)
         q.put((rank, sc.simtime, g.download(0)))
@@ -37,14 +38,29 @@ def _worker(rank, world, port, case, nsteps, q):
     dist.destroy_process_group()
 
 
+def _setup(case, sim, cfg):
+    """cooling tables, this grid's (or slab's) wind cells; returns the first-step dt limit"""
+    if case != "wind3d":
+        return None
+    from pion_amd import cooling, problems
+    sim.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
+    _, (idx, st), dt_lim = problems.fill_wind3d(cfg, 16)
+    if idx.size:
+        sim.set_wind_cells(idx, st)
+    return dt_lim
+
+
 def _case(case):
     from pion_amd import abi, problems
+    if case == "wind3d":
+        cfg, P, _, _ = problems.wind3d(16, strict_fp=1)
+        return cfg, P
     if case == "glm_periodic":
         return problems.mhd_blastwave(16, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
     return problems.hd_blast_octant(16, 3, solver=abi.FLUX_RSroe, strict_fp=1, nzones=3.0)
 
 
-@pytest.mark.parametrize("case", ["glm_periodic", "hd_octant"])
+@pytest.mark.parametrize("case", ["glm_periodic", "hd_octant", "wind3d"])
 def test_two_gpu_ranks_match_single_domain(case):
     import torch.multiprocessing as mp
     from pion_amd import driver, lib
@@ -52,6 +68,7 @@ def test_two_gpu_ranks_match_single_domain(case):
     cfg, P = _case(case)
     with lib.GpuSim(cfg, 0) as g:
         sc = driver.SimControl(g, cfg)
+        sc.first_step_dt_limit = _setup(case, g, cfg)
         sc.init(P)
         sc.time_int(nsteps)
         ref, tref = g.download(0), sc.simtime
