@@ -99,6 +99,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
                          "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
+    ap.add_argument("--nz", type=int, default=0,
+                    help="m1 only: cells along z if not --n (with --loopback and nz = n/N this is exactly the slab, the "
+                         "launches and the transfers of one rank of an N-rank run)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="one rank, m1 only: the periodic z faces become slab faces that exchange with the rank itself "
+                         "over RCCL (send/recv to self on the comm stream, split stages) -- the whole N>1 code path on a "
+                         "one-GPU box; the step cost over the plain run is the split + exchange overhead")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +131,14 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("gloo")
 
+    loopback = args.loopback and world == 1 and args.workload == "m1"
+    if loopback:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (23400 + os.getpid() % 4000),
+                                rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
     n = args.n
     wl_name = None
     dt_lim = None
@@ -131,8 +146,12 @@ def main():
     if args.workload == "m1":
         cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
         cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
+        if args.nz:
+            cfg_g.ng[2] = args.nz
         cfg_g.dx = 1.0 / n
         cfg = slab.slab_config(cfg_g, rank, world)
+        if loopback:
+            cfg.bc_type[4] = cfg.bc_type[5] = abi.BC_SLAB
         P = problems.fill_mhd_blastwave(cfg)
         sim = lib.GpuSim(cfg, local_rank)
     elif args.workload == "m2":
@@ -164,8 +183,9 @@ def main():
         if widx.size:
             sim.set_wind_cells(widx, wst)   # (ranks away from the source hold no wind cell)
         eq = cfg.eqntype
-    if world > 1:
-        comm = slab.SlabComm(rank, world, periodic_z, sim.halo_count(), torch.device("cuda", local_rank))
+    if world > 1 or loopback:
+        comm = slab.SlabComm(rank, world, periodic_z, sim.halo_count(), torch.device("cuda", local_rank),
+                             loopback=loopback)
         comm.use_streams(sim)   # exchange under the interior part of each stage, no host waits
     sc = driver.SimControl(sim, cfg, comm=comm)
     sc.first_step_dt_limit = dt_lim
@@ -175,7 +195,7 @@ def main():
     def barrier():
         sc.finish_halo()
         sim.synchronize()
-        if world > 1:
+        if world > 1 or loopback:
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -197,7 +217,7 @@ def main():
         el = float(t.item())
 
     if rank == 0:
-        ncell = n ** 3
+        ncell = cfg_g.ng[0] * cfg_g.ng[1] * cfg_g.ng[2]
         value = ncell * args.steps / el / 1e6
         nvar = cfg.nvar
         # algorithmic bytes of one stage launch on this rank: a step moves 5*nvar*8 B per
@@ -214,7 +234,7 @@ def main():
         # when it is for this workload (512^3, GLM, fast mode, 1 GPU); otherwise null.
         traffic = None
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if (world == 1 and n == 512 and eq == abi.EQGLM and not args.strict and args.workload == "m1"
+        if (world == 1 and not loopback and n == 512 and eq == abi.EQGLM and not args.strict and args.workload == "m1"
                 and os.path.exists(tfile)):
             with open(tfile) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -237,7 +257,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name or "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
                                    % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
-                       "grid": [n, n, n], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": "none" if world == 1 else
+                       "grid": [int(v) for v in cfg_g.ng[:3]], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": "RCCL send/recv to self (loopback)" if loopback else "none" if world == 1 else
                        ("RCCL P2P" if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"),
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -252,7 +272,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, eq, solver)
         print(json.dumps(out))
     sim.close()
-    if world > 1:
+    if world > 1 or loopback:
         dist.destroy_process_group()
 
 

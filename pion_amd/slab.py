@@ -60,8 +60,11 @@ class SlabComm:
     tensor on the device the backend computes on; backend.pack_halo/unpack_halo take
     (which, face, tensor.data_ptr())."""
 
-    def __init__(self, rank, world, periodic, halo_count, device, host_staged=None):
-        """host_staged: exchange through pinned host buffers (GPU state, CPU-only backend such as
+    def __init__(self, rank, world, periodic, halo_count, device, host_staged=None, loopback=False):
+        """loopback: a single rank with periodic z whose z faces are BC_SLAB exchanges with itself
+        through the backend (the only way to drive RCCL send/recv on a one-GPU box); the result
+        equals the periodic single-domain run.
+        host_staged: exchange through pinned host buffers (GPU state, CPU-only backend such as
         gloo: rehearsals of the multi-rank GPU path on a box without RCCL peers).  Default: staged iff
         the device is a GPU and the process group's backend is not nccl."""
         import torch
@@ -70,13 +73,14 @@ class SlabComm:
         self.rank, self.world = rank, world
         self.up = (rank + 1) % world if (periodic or rank < world - 1) else None
         self.down = (rank - 1) % world if (periodic or rank > 0) else None
+        self.loopback = bool(loopback and world == 1 and periodic)
         if world == 1:
-            self.up = self.down = None
+            self.up = self.down = (rank if self.loopback else None)
         device = torch.device(device)
         mk = lambda: torch.empty(halo_count, dtype=torch.float64, device=device)
         self.send_up, self.send_down, self.recv_up, self.recv_down = mk(), mk(), mk(), mk()
         if host_staged is None:
-            host_staged = (device.type == "cuda" and world > 1 and dist.is_initialized()
+            host_staged = (device.type == "cuda" and (world > 1 or self.loopback) and dist.is_initialized()
                            and dist.get_backend() != "nccl")
         self.host_staged = bool(host_staged)
         if self.host_staged:
@@ -165,7 +169,7 @@ class SlabComm:
         self.finish(sim)
 
     def allreduce_min(self, t_dyn, t_mp):
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return t_dyn, t_mp
         self.dtbuf[0] = t_dyn
         self.dtbuf[1] = t_mp
