@@ -42,6 +42,34 @@ enum { ERR_NEG_DENSITY = 1, ERR_RIEMANN_INPUT = 2, ERR_COOLING = 4, ERR_BAD_DT =
 // std::max / std::min semantics (not fmax/fmin: NaN behaviour differs)
 PDEV double dmax(double a, double b) { return (a < b) ? b : a; }
 PDEV double dmin(double a, double b) { return (b < a) ? b : a; }
+#ifdef PION_FAST_MATH
+// Fast build only.  One-instruction max/min (a NaN operand is dropped instead of, in one of the two
+// argument orders, returned: only differs for states that are already in error).
+PDEV double fmx(double a, double b) { return __builtin_fmax(a, b); }
+PDEV double fmn(double a, double b) { return __builtin_fmin(a, b); }
+// sqrt(x) and 1/sqrt(x) of a positive, normal x: v_rsq_f64 seed, one coupled Goldschmidt step, one
+// residual correction of the root (<= 1 ulp; the reciprocal root to a few ulp).  Against the library
+// form this drops the range scaling (operands are squares and ratios of cgs-scale state variables, far
+// from the subnormal and overflow ranges), the second correction and the zero/infinity fix-up:
+// x = 0 gives NaN, so callers pass operands that are positive by construction.
+PDEV void sqrt_rsqrt_pos(const double x, double &root, double &rroot)
+{
+  const double y = __builtin_amdgcn_rsq(x);
+  double gq = x * y, hq = 0.5 * y;
+  const double r = __builtin_fma(-hq, gq, 0.5);
+  gq = __builtin_fma(gq, r, gq);
+  hq = __builtin_fma(hq, r, hq);
+  const double d = __builtin_fma(-gq, gq, x);
+  root = __builtin_fma(d, hq, gq);
+  rroot = hq + hq;
+}
+PDEV double sqrt_pos(const double x)
+{
+  double s, rs;
+  sqrt_rsqrt_pos(x, s, rs);
+  return s;
+}
+#endif
 
 template <int EQ>
 struct EqBase {
@@ -137,8 +165,8 @@ struct Eqn {
     const double ir = 1.0 / cfRO;
     const double a2 = g * cfPG * ir;
     const double temp1 = a2 + (cfBX * cfBX + cfBY * cfBY + cfBZ * cfBZ) * ir;
-    const double temp2 = dmax(PION_MACHINEACCURACY, temp1 * temp1 - 4. * a2 * cfBX * cfBX * ir);
-    return (sqrt((temp1 + sqrt(temp2)) * 0.5));
+    const double temp2 = fmx(PION_MACHINEACCURACY, temp1 * temp1 - 4. * a2 * cfBX * cfBX * ir);
+    return sqrt_pos((temp1 + sqrt_pos(temp2)) * 0.5);
 #else
     double ch = sqrt(g * cfPG / cfRO);
     double temp1 = ch * ch + (cfBX * cfBX + cfBY * cfBY + cfBZ * cfBZ) / cfRO;

@@ -701,11 +701,12 @@ struct Flux {
       const double a2l = g * Pl[qPG] * irl, a2r = g * Pr[qPG] * irr;
       const double t1l = a2l + (BX2 + Pl[qBT1] * Pl[qBT1] + Pl[qBT2] * Pl[qBT2]) * irl;
       const double t1r = a2r + (BX2 + Pr[qBT1] * Pr[qBT1] + Pr[qBT2] * Pr[qBT2]) * irr;
-      const double t2l = dmax(PION_MACHINEACCURACY, t1l * t1l - 4. * a2l * BX2 * irl);
-      const double t2r = dmax(PION_MACHINEACCURACY, t1r * t1r - 4. * a2r * BX2 * irr);
-      cfm = dmax(sqrt((t1l + sqrt(t2l)) * 0.5), sqrt((t1r + sqrt(t2r)) * 0.5));
+      const double t2l = fmx(PION_MACHINEACCURACY, t1l * t1l - 4. * a2l * BX2 * irl);
+      const double t2r = fmx(PION_MACHINEACCURACY, t1r * t1r - 4. * a2r * BX2 * irr);
+      // max of the two fast speeds: the root is monotonic, so one outer root of the larger argument
+      cfm = sqrt_pos(fmx(t1l + sqrt_pos(t2l), t1r + sqrt_pos(t2r)) * 0.5);
     }
-    const double SL = dmin(Pl[qVN], Pr[qVN]) - cfm, SR = dmax(Pl[qVN], Pr[qVN]) + cfm;
+    const double SL = fmn(Pl[qVN], Pr[qVN]) - cfm, SR = fmx(Pl[qVN], Pr[qVN]) + cfm;
     const double sl_vl = SL - Pl[qVN], sr_vr = SR - Pr[qVN];
     const double ptl = E::mhd_Ptot(Pl), ptr = E::mhd_Ptot(Pr);
     const double rsl = Pl[qRO] * sl_vl, rsr = Pr[qRO] * sr_vr;
@@ -719,31 +720,30 @@ struct Flux {
     double vys_r = Pr[qVT1], vzs_r = Pr[qVT2], bys_r = 0.0, bzs_r = 0.0;
     {
       const double den = 1.0 / (rsl * sl_sm - BX2);
-      const double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
-      if (isfinite(q1)) {
-        vys_l = Pl[qVT1] - BX * Pl[qBT1] * q1;
-        vzs_l = Pl[qVT2] - BX * Pl[qBT2] * q1;
-      }
-      if (isfinite(q2)) {
-        bys_l = Pl[qBT1] * q2;
-        bzs_l = Pl[qBT2] * q2;
-      }
+      // a non-finite factor leaves the tangential state as it is: zero it (one select per factor)
+      double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
+      q1 = isfinite(q1) ? q1 : 0.0;
+      q2 = isfinite(q2) ? q2 : 0.0;
+      vys_l = Pl[qVT1] - BX * Pl[qBT1] * q1;
+      vzs_l = Pl[qVT2] - BX * Pl[qBT2] * q1;
+      bys_l = Pl[qBT1] * q2;
+      bzs_l = Pl[qBT2] * q2;
     }
     {
       const double den = 1.0 / (rsr * sr_sm - BX2);
-      const double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
-      if (isfinite(q1)) {
-        vys_r = Pr[qVT1] - BX * Pr[qBT1] * q1;
-        vzs_r = Pr[qVT2] - BX * Pr[qBT2] * q1;
-      }
-      if (isfinite(q2)) {
-        bys_r = Pr[qBT1] * q2;
-        bzs_r = Pr[qBT2] * q2;
-      }
+      double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
+      q1 = isfinite(q1) ? q1 : 0.0;
+      q2 = isfinite(q2) ? q2 : 0.0;
+      vys_r = Pr[qVT1] - BX * Pr[qBT1] * q1;
+      vzs_r = Pr[qVT2] - BX * Pr[qBT2] * q1;
+      bys_r = Pr[qBT1] * q2;
+      bzs_r = Pr[qBT2] * q2;
     }
-    const double sql = sqrt(rosl), sqr = sqrt(rosr);
+    double sql, sqr, isql, isqr;   // rho*_K > 0 (S_K - v_K and S_K - S_M have the same sign)
+    sqrt_rsqrt_pos(rosl, sql, isql);
+    sqrt_rsqrt_pos(rosr, sqr, isqr);
     const double aBX = fabs(BX);
-    const double SsL = SM - aBX / sql, SsR = SM + aBX / sqr;
+    const double SsL = SM - aBX * isql, SsR = SM + aBX * isqr;
     // Alfven-averaged state
     const double sgn = (double)((BX > 0) - (BX < 0));
     const double isum = 1.0 / (sql + sqr);
@@ -791,14 +791,25 @@ struct Flux {
     Uss[uBN] = BX;
     Uss[uBT1] = by_ss;
     Uss[uBT2] = bz_ss;
-    Uss[uERG] = left ? Us[uERG] - sqK * (vBs - vBss) * sgn : Us[uERG] + sqK * (vBs - vBss) * sgn;
+    Uss[uERG] = Us[uERG] + sqK * (vBs - vBss) * (left ? -sgn : sgn);
+    // the region selects act on the two wave speeds, not on the eight components (the star states
+    // are finite whenever the inputs are: S_K - S_M and rho*_K keep their signs in every region)
+    const double c1 = w1 ? SK : 0.0, c2 = w2 ? SsK : 0.0;
 #pragma unroll
     for (int v = 0; v < 8; v++) {
       const double d1 = Us[v] - UK[v], d2 = Uss[v] - Us[v];
-      const double a1 = w1 ? SK * d1 : 0.0, a2 = w2 ? SsK * d2 : 0.0;
-      out_flux[v] = FK[v] + a1 + a2;
-      out_ustar[v] = (r2L || r2R) ? (w2 ? Uss[v] : Us[v]) : (w1 ? Us[v] : UK[v]);
+      out_flux[v] = FK[v] + c1 * d1 + c2 * d2;
     }
+    // resolved state: U** in the inner regions (w2), U* behind a fast wave (w1), else U_K; rho, the
+    // normal momentum and B_n are the same in U* and U**
+    out_ustar[uRHO] = w1 ? Us[uRHO] : UK[uRHO];
+    out_ustar[uMN] = w1 ? Us[uMN] : UK[uMN];
+    out_ustar[uBN] = w1 ? Us[uBN] : UK[uBN];
+    out_ustar[uMT1] = w2 ? Uss[uMT1] : (w1 ? Us[uMT1] : UK[uMT1]);
+    out_ustar[uMT2] = w2 ? Uss[uMT2] : (w1 ? Us[uMT2] : UK[uMT2]);
+    out_ustar[uBT1] = w2 ? Uss[uBT1] : (w1 ? Us[uBT1] : UK[uBT1]);
+    out_ustar[uBT2] = w2 ? Uss[uBT2] : (w1 ? Us[uBT2] : UK[uBT2]);
+    out_ustar[uERG] = w2 ? Uss[uERG] : (w1 ? Us[uERG] : UK[uERG]);
   }
 #else
   static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar)
