@@ -714,7 +714,8 @@ struct Flux {
     const double SM = (rsr * Pr[qVN] - rsl * Pl[qVN] - ptr + ptl) * itemp;
     const double pts = (rsr * ptl - rsl * ptr + rsl * rsr * (Pr[qVN] - Pl[qVN])) * itemp;
     const double sl_sm = SL - SM, sr_sm = SR - SM;
-    const double rosl = rsl / sl_sm, rosr = rsr / sr_sm;
+    const double isl_sm = 1.0 / sl_sm, isr_sm = 1.0 / sr_sm;   // (one of them is reused for U*_K below)
+    const double rosl = rsl * isl_sm, rosr = rsr * isr_sm;
     // tangential velocity and field behind the fast waves, both sides (the ** state needs both)
     double vys_l = Pl[qVT1], vzs_l = Pl[qVT2], bys_l = 0.0, bzs_l = 0.0;
     double vys_r = Pr[qVT1], vzs_r = Pr[qVT2], bys_r = 0.0, bzs_r = 0.0;
@@ -765,7 +766,7 @@ struct Flux {
 #pragma unroll
     for (int v = 0; v < 8; v++) PK[v] = left ? Pl[v] : Pr[v];
     const double SK = left ? SL : SR, SsK = left ? SsL : SsR;
-    const double sK_vK = left ? sl_vl : sr_vr, isK_sm = 1.0 / (left ? sl_sm : sr_sm);
+    const double sK_vK = left ? sl_vl : sr_vr, isK_sm = left ? isl_sm : isr_sm;
     const double rosK = left ? rosl : rosr, sqK = left ? sql : sqr, ptK = left ? ptl : ptr;
     const double vysK = left ? vys_l : vys_r, vzsK = left ? vzs_l : vzs_r;
     const double bysK = left ? bys_l : bys_r, bzsK = left ? bzs_l : bzs_r;

@@ -47,6 +47,9 @@ PDEV int rotvar(const int ax, const int s)
   }
   return s;
 }
+template <int EQ, int NV>
+PDEV void apply_axis(double *d, const double *q0, const double bnm, const double sim, const double bnp,
+                     const double sip, const double *Fm, const double *Fp, const double dt, const double dx);
 // BaseVectorOps::AvgFalle with AVG_MINMOD (coord_sys/VectorOps.cpp:37-59)
 PDEV double avg_falle(const double a, const double b)
 {
@@ -324,6 +327,26 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
     // accumulate in the sweep frame, in the reference's order
     double d[NV];
     to_sweep<NV, MHD>(ax, dU, d);
+#ifdef PION_FAST_MATH
+    // fast build, Cartesian axis: the same regrouped source + flux-difference update as k_stage_rows
+    // (apply_axis), so that the two kernels agree to rounding
+    const bool fast_cart = !cylR && !sphR;
+#else
+    const bool fast_cart = false;
+#endif
+    if (fast_cart) {
+      double bnm_ = 0.0, bnp_ = 0.0, sim_ = 0.0, sip_ = 0.0;
+      if constexpr (MHD) {
+        bnm_ = qm1[qBN];
+        bnp_ = qp1[qBN];
+      }
+      if constexpr (EQ == EQGLM) {
+        sim_ = qm1[qSI];
+        sip_ = qp1[qSI];
+      }
+      apply_axis<EQ, NV>(d, q0, bnm_, sim_, bnp_, sip_, Fm, Fp, dt, dx);
+    }
+    else {
     if constexpr (MHD) {
       // MHDsource (solver_eqn_mhd_adi.cpp:396-443, GLM :782-813): this cell is the right cell
       // of face 0 and the left cell of face 1
@@ -436,6 +459,7 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
         const double u1 = (Fm[s] - Fp[s]) / dx;
         d[s] += dt * u1;
       }
+    }
     }
     from_sweep<NV, MHD>(ax, d, dU);
   }

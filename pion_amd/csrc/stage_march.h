@@ -44,6 +44,31 @@ template <int EQ, int NV>
 PDEV void apply_axis(double *d, const double *q0, const double bnm, const double sim, const double bnp,
                      const double sip, const double *Fm, const double *Fp, const double dt, const double dx)
 {
+#ifdef PION_FAST_MATH
+  // fast build: the two face terms of the Powell (and GLM) source share their state factor, and the
+  // face means differ by (B_n^- - B_n^+)/2: one fused multiply-add per component (the reference adds
+  // the lower-face and subtracts the upper-face term separately; same sum up to rounding)
+  const double dtdx = dt / dx;
+  if constexpr (EQ != EQEUL) {
+    const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
+    const double kb = dtdx * (0.5 * (bnm - bnp));
+    d[uMN] += kb * q0[qBN];
+    d[uMT1] += kb * q0[qBT1];
+    d[uMT2] += kb * q0[qBT2];
+    d[uERG] += kb * uB;
+    d[uBN] += kb * q0[qVN];
+    d[uBT1] += kb * q0[qVT1];
+    d[uBT2] += kb * q0[qVT2];
+    if constexpr (EQ == EQGLM) {
+      const double ks = dtdx * (0.5 * (sim - sip)) * q0[qVN];
+      d[uERG] += ks * q0[qSI];
+      d[uPSI] += ks;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NV; s++) d[s] += dtdx * (Fm[s] - Fp[s]);
+  return;
+#endif
   if constexpr (EQ != EQEUL) {
     const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
     const double bm0 = 0.5 * (bnm + q0[qBN]);
