@@ -69,6 +69,15 @@ PDEV double sqrt_pos(const double x)
   sqrt_rsqrt_pos(x, s, rs);
   return s;
 }
+// root of a quantity that is positive for every valid state (density, gamma p / rho, ...); max / min
+// of finite operands: the fast forms in the fast build, the reference's in the strict build
+PDEV double psqrt(const double x) { return sqrt_pos(x); }
+PDEV double pmax(const double a, const double b) { return fmx(a, b); }
+PDEV double pmin(const double a, const double b) { return fmn(a, b); }
+#else
+PDEV double psqrt(const double x) { return sqrt(x); }
+PDEV double pmax(const double a, const double b) { return dmax(a, b); }
+PDEV double pmin(const double a, const double b) { return dmin(a, b); }
 #endif
 
 template <int EQ>
@@ -94,7 +103,11 @@ PDEV bool equalD(const double a, const double b)
 {
   if (a == b) return true;
   if (fabs(a) + fabs(b) < PION_TINYVALUE) return true;
+#ifdef PION_FAST_MATH
+  if (fabs(a - b) < PION_SMALLVALUE * (fabs(a) + fabs(b) + PION_TINYVALUE)) return true;  // no division
+#else
   if ((fabs(a - b) / (fabs(a) + fabs(b) + PION_TINYVALUE)) < PION_SMALLVALUE) return true;
+#endif
   return false;
 }
 
@@ -113,7 +126,7 @@ struct Eqn {
     u[uMT2] = p[qRO] * p[qVT2];
     u[uERG] = p[qRO] * (p[qVN] * p[qVN] + p[qVT1] * p[qVT1] + p[qVT2] * p[qVT2]) * 0.5 + p[qPG] / (g - 1.);
   }
-  static PDEV double chydro(const double *p, const double g) { return sqrt(g * p[qPG] / p[qRO]); }
+  static PDEV double chydro(const double *p, const double g) { return psqrt(g * p[qPG] / p[qRO]); }
   static PDEV void euler_PUtoFlux(const double *p, const double *u, double *f)
   {
     f[uRHO] = u[uMN];

@@ -63,7 +63,7 @@ struct Flux {
                           double *out_pstar, double *out_flux)
   {
     double meanp[5], ul[5], ur[5], eval[5], strength[5], udiff[5];
-    double rl = sqrt(left[qRO]), rr = sqrt(right[qRO]), lH = E::Enthalpy(left, g), rH = E::Enthalpy(right, g),
+    double rl = psqrt(left[qRO]), rr = psqrt(right[qRO]), lH = E::Enthalpy(left, g), rH = E::Enthalpy(right, g),
            denom = 1.0 / (rl + rr);
     meanp[qRO] = rl * rr;
     meanp[qVN] = (rl * left[qVN] + rr * right[qVN]) * denom;
@@ -72,14 +72,14 @@ struct Flux {
     meanp[qPG] = (rl * lH + rr * rH) * denom;  // enthalpy lives in the pressure slot
     const double HH = meanp[qPG];
     double v2_mean = meanp[qVN] * meanp[qVN] + meanp[qVT1] * meanp[qVT1] + meanp[qVT2] * meanp[qVT2];
-    double a_mean = sqrt((g - 1.0) * dmax(HH - 0.5 * v2_mean, 1.0e-12 * v2_mean));
+    double a_mean = psqrt((g - 1.0) * pmax(HH - 0.5 * v2_mean, 1.0e-12 * v2_mean));
     eval[0] = meanp[qVN] - a_mean;
     eval[1] = eval[2] = eval[3] = meanp[qVN];
     eval[4] = meanp[qVN] + a_mean;
 #pragma unroll
     for (int v = 0; v < 5; v++) {
-      if (eval[v] < 0.0) eval[v] = dmin(eval[v], -hc_eta);
-      else eval[v] = dmax(eval[v], hc_eta);
+      if (eval[v] < 0.0) eval[v] = pmin(eval[v], -hc_eta);
+      else eval[v] = pmax(eval[v], hc_eta);
     }
     // right eigenvectors, Toro eq. 11.59, rows indexed by conserved slot
     double evec[5][5];
@@ -204,7 +204,7 @@ struct Flux {
     }
 #pragma unroll
     for (int v = 0; v < 5; v++) flux[v] = fpos[v] + fneg[v];
-    double RoeAvg_rl = sqrt(pl[qRO]), RoeAvg_rr = sqrt(pr[qRO]), RoeAvg_denom = 1.0 / (RoeAvg_rl + RoeAvg_rr);
+    double RoeAvg_rl = psqrt(pl[qRO]), RoeAvg_rr = psqrt(pr[qRO]), RoeAvg_denom = 1.0 / (RoeAvg_rl + RoeAvg_rr);
     pstar[qRO] = RoeAvg_rl * RoeAvg_rr;
     pstar[qVN] = (RoeAvg_rl * pl[qVN] + RoeAvg_rr * pr[qVN]) * RoeAvg_denom;
     pstar[qVT1] = (RoeAvg_rl * pl[qVT1] + RoeAvg_rr * pr[qVT1]) * RoeAvg_denom;

@@ -109,6 +109,15 @@ def test_fast_mode_tolerance():
     run_pair(cfg, P, 3, strict=False, tol=1e-11)
 
 
+@pytest.mark.parametrize("solver", [abi.FLUX_RSroe, abi.FLUX_FVS, abi.FLUX_RS_HLL])
+def test_fast_mode_tolerance_hd(solver):
+    """Production (fast) Euler kernels against the oracle on a 3-D blast with a tracer: FMA contraction,
+    rsq-seeded roots and the division-free equalD move results by rounding only (1e-10 of each
+    variable's scale after three steps across a shock)."""
+    cfg, P = problems.hd_blast_octant(20, 3, solver=solver, ntracer=1, strict_fp=0, nzones=3.0)
+    run_pair(cfg, P, 3, strict=False, tol=1e-10)
+
+
 @pytest.mark.parametrize("eq,solvers", [(abi.EQEUL, [0, 1, 2, 3, 4, 5, 6, 8]), (abi.EQMHD, [0, 7, 8]), (abi.EQGLM, [0, 7, 8])])
 def test_interface_flux_strict(eq, solvers):
     rng = np.random.default_rng(7)
