@@ -796,11 +796,15 @@ struct Flux {
     // the region selects act on the two wave speeds, not on the eight components (the star states
     // are finite whenever the inputs are: S_K - S_M and rho*_K keep their signs in every region)
     const double c1 = w1 ? SK : 0.0, c2 = w2 ? SsK : 0.0;
-#pragma unroll
-    for (int v = 0; v < 8; v++) {
-      const double d1 = Us[v] - UK[v], d2 = Uss[v] - Us[v];
-      out_flux[v] = FK[v] + c1 * d1 + c2 * d2;
-    }
+    // (rho, the normal momentum and B_n do not change across the rotational wave: no c2 term)
+    out_flux[uRHO] = FK[uRHO] + c1 * (Us[uRHO] - UK[uRHO]);
+    out_flux[uMN] = FK[uMN] + c1 * (Us[uMN] - UK[uMN]);
+    out_flux[uBN] = FK[uBN] + c1 * (Us[uBN] - UK[uBN]);
+    out_flux[uMT1] = FK[uMT1] + c1 * (Us[uMT1] - UK[uMT1]) + c2 * (Uss[uMT1] - Us[uMT1]);
+    out_flux[uMT2] = FK[uMT2] + c1 * (Us[uMT2] - UK[uMT2]) + c2 * (Uss[uMT2] - Us[uMT2]);
+    out_flux[uBT1] = FK[uBT1] + c1 * (Us[uBT1] - UK[uBT1]) + c2 * (Uss[uBT1] - Us[uBT1]);
+    out_flux[uBT2] = FK[uBT2] + c1 * (Us[uBT2] - UK[uBT2]) + c2 * (Uss[uBT2] - Us[uBT2]);
+    out_flux[uERG] = FK[uERG] + c1 * (Us[uERG] - UK[uERG]) + c2 * (Uss[uERG] - Us[uERG]);
     // resolved state: U** in the inner regions (w2), U* behind a fast wave (w1), else U_K; rho, the
     // normal momentum and B_n are the same in U* and U**
     out_ustar[uRHO] = w1 ? Us[uRHO] : UK[uRHO];
@@ -1433,7 +1437,11 @@ struct Flux {
       momvisc = prefactor * (Pr[qVT2] - Pl[qVT2]);
       flux[uMT2] -= momvisc;
       ergvisc += momvisc * pstar[qVT2];
+#ifdef PION_FAST_MATH
+      prefactor *= 1.0 / pstar[qRO];   // (= etav / (etav rho*); shares the reciprocal UtoP already formed)
+#else
       prefactor *= c.etav / (c.etav * pstar[qRO]);
+#endif
       momvisc = prefactor * (Pr[qBT1] - Pl[qBT1]);
       flux[uBT1] -= momvisc;
       ergvisc += momvisc * pstar[qBT1];
