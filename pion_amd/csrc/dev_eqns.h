@@ -47,6 +47,17 @@ PDEV double dmin(double a, double b) { return (b < a) ? b : a; }
 // argument orders, returned: only differs for states that are already in error).
 PDEV double fmx(double a, double b) { return __builtin_fmax(a, b); }
 PDEV double fmn(double a, double b) { return __builtin_fmin(a, b); }
+// 1/x: v_rcp_f64 seed (measured 2^-24.4 on gfx950, profiles/tools/seed_precision.hip) and two Newton steps
+// (2^-53); the compiler's own expansion under -freciprocal-math runs three.  0 and infinity give NaN, as
+// there.
+PDEV double frcp(const double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
 // sqrt(x) and 1/sqrt(x) of a positive, normal x: v_rsq_f64 seed, one coupled Goldschmidt step, one
 // residual correction of the root (<= 1 ulp; the reciprocal root to a few ulp).  Against the library
 // form this drops the range scaling (operands are squares and ratios of cgs-scale state variables, far
@@ -175,7 +186,7 @@ struct Eqn {
   {
 #ifdef PION_FAST_MATH
     // fast build: a^2 = gamma p / rho directly (the strict form squares its square root), one reciprocal
-    const double ir = 1.0 / cfRO;
+    const double ir = frcp(cfRO);
     const double a2 = g * cfPG * ir;
     const double temp1 = a2 + (cfBX * cfBX + cfBY * cfBY + cfBZ * cfBZ) * ir;
     const double temp2 = fmx(PION_MACHINEACCURACY, temp1 * temp1 - 4. * a2 * cfBX * cfBX * ir);
@@ -254,9 +265,16 @@ struct Eqn {
     for (int t = 0; t < NTR; t++) p[BASE + t] = u[BASE + t] / u[uRHO];
     if constexpr (EQ == EQGLM) p[qSI] = u[uPSI];
     p[qRO] = u[uRHO];
+#ifdef PION_FAST_MATH
+    const double iro = frcp(u[uRHO]);
+    p[qVN] = u[uMN] * iro;
+    p[qVT1] = u[uMT1] * iro;
+    p[qVT2] = u[uMT2] * iro;
+#else
     p[qVN] = u[uMN] / u[uRHO];
     p[qVT1] = u[uMT1] / u[uRHO];
     p[qVT2] = u[uMT2] / u[uRHO];
+#endif
     if constexpr (EQ == EQEUL) {
       p[qPG] = (g - 1.0) * (u[uERG] - p[qRO] * (p[qVN] * p[qVN] + p[qVT1] * p[qVT1] + p[qVT2] * p[qVT2]) / 2.0);
     }

@@ -694,7 +694,7 @@ struct Flux {
   {
     const double BX = 0.5 * (Pl[qBN] + Pr[qBN]);
     const double BX2 = BX * BX;
-    const double irl = 1.0 / Pl[qRO], irr = 1.0 / Pr[qRO];
+    const double irl = frcp(Pl[qRO]), irr = frcp(Pr[qRO]);
     // HLLD_signal_speeds with B_n := BX
     double cfm;
     {
@@ -710,17 +710,17 @@ struct Flux {
     const double sl_vl = SL - Pl[qVN], sr_vr = SR - Pr[qVN];
     const double ptl = E::mhd_Ptot(Pl), ptr = E::mhd_Ptot(Pr);
     const double rsl = Pl[qRO] * sl_vl, rsr = Pr[qRO] * sr_vr;
-    const double itemp = 1.0 / (rsr - rsl);
+    const double itemp = frcp(rsr - rsl);
     const double SM = (rsr * Pr[qVN] - rsl * Pl[qVN] - ptr + ptl) * itemp;
     const double pts = (rsr * ptl - rsl * ptr + rsl * rsr * (Pr[qVN] - Pl[qVN])) * itemp;
     const double sl_sm = SL - SM, sr_sm = SR - SM;
-    const double isl_sm = 1.0 / sl_sm, isr_sm = 1.0 / sr_sm;   // (one of them is reused for U*_K below)
+    const double isl_sm = frcp(sl_sm), isr_sm = frcp(sr_sm);   // (one of them is reused for U*_K below)
     const double rosl = rsl * isl_sm, rosr = rsr * isr_sm;
     // tangential velocity and field behind the fast waves, both sides (the ** state needs both)
     double vys_l = Pl[qVT1], vzs_l = Pl[qVT2], bys_l = 0.0, bzs_l = 0.0;
     double vys_r = Pr[qVT1], vzs_r = Pr[qVT2], bys_r = 0.0, bzs_r = 0.0;
     {
-      const double den = 1.0 / (rsl * sl_sm - BX2);
+      const double den = frcp(rsl * sl_sm - BX2);
       // a non-finite factor leaves the tangential state as it is: zero it (one select per factor)
       double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
       q1 = isfinite(q1) ? q1 : 0.0;
@@ -731,7 +731,7 @@ struct Flux {
       bzs_l = Pl[qBT2] * q2;
     }
     {
-      const double den = 1.0 / (rsr * sr_sm - BX2);
+      const double den = frcp(rsr * sr_sm - BX2);
       double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
       q1 = isfinite(q1) ? q1 : 0.0;
       q2 = isfinite(q2) ? q2 : 0.0;
@@ -747,7 +747,7 @@ struct Flux {
     const double SsL = SM - aBX * isql, SsR = SM + aBX * isqr;
     // Alfven-averaged state
     const double sgn = (double)((BX > 0) - (BX < 0));
-    const double isum = 1.0 / (sql + sqr);
+    const double isum = frcp(sql + sqr);
     const double vy_ss = (sql * vys_l + sqr * vys_r + (bys_r - bys_l) * sgn) * isum;
     const double vz_ss = (sql * vzs_l + sqr * vzs_r + (bzs_r - bzs_l) * sgn) * isum;
     const double by_ss = (sql * bys_r + sqr * bys_l + sql * sqr * (vys_r - vys_l) * sgn) * isum;
@@ -1438,7 +1438,7 @@ struct Flux {
       flux[uMT2] -= momvisc;
       ergvisc += momvisc * pstar[qVT2];
 #ifdef PION_FAST_MATH
-      prefactor *= 1.0 / pstar[qRO];   // (= etav / (etav rho*); shares the reciprocal UtoP already formed)
+      prefactor *= frcp(pstar[qRO]);   // (= etav / (etav rho*); the same reciprocal UtoP forms)
 #else
       prefactor *= c.etav / (c.etav * pstar[qRO]);
 #endif
