@@ -83,10 +83,12 @@ PDEV double sqrt_pos(const double x)
 // root of a quantity that is positive for every valid state (density, gamma p / rho, ...); max / min
 // of finite operands: the fast forms in the fast build, the reference's in the strict build
 PDEV double psqrt(const double x) { return sqrt_pos(x); }
+PDEV double prcp(const double x) { return frcp(x); }
 PDEV double pmax(const double a, const double b) { return fmx(a, b); }
 PDEV double pmin(const double a, const double b) { return fmn(a, b); }
 #else
 PDEV double psqrt(const double x) { return sqrt(x); }
+PDEV double prcp(const double x) { return 1.0 / x; }   // (only used in fast-build branches)
 PDEV double pmax(const double a, const double b) { return dmax(a, b); }
 PDEV double pmin(const double a, const double b) { return dmin(a, b); }
 #endif
@@ -137,7 +139,11 @@ struct Eqn {
     u[uMT2] = p[qRO] * p[qVT2];
     u[uERG] = p[qRO] * (p[qVN] * p[qVN] + p[qVT1] * p[qVT1] + p[qVT2] * p[qVT2]) * 0.5 + p[qPG] / (g - 1.);
   }
-  static PDEV double chydro(const double *p, const double g) { return psqrt(g * p[qPG] / p[qRO]); }
+#ifdef PION_FAST_MATH
+  static PDEV double chydro(const double *p, const double g) { return sqrt_pos(g * p[qPG] * frcp(p[qRO])); }
+#else
+  static PDEV double chydro(const double *p, const double g) { return sqrt(g * p[qPG] / p[qRO]); }
+#endif
   static PDEV void euler_PUtoFlux(const double *p, const double *u, double *f)
   {
     f[uRHO] = u[uMN];
@@ -148,6 +154,18 @@ struct Eqn {
   }
   static PDEV void euler_UtoFlux(const double *u, double *f, const double g)
   {
+#ifdef PION_FAST_MATH
+    {
+      const double iro = frcp(u[uRHO]), vn = u[uMN] * iro;
+      const double pgf = (g - 1.) * (u[uERG] - (u[uMN] * u[uMN] + u[uMT1] * u[uMT1] + u[uMT2] * u[uMT2]) * 0.5 * iro);
+      f[uRHO] = u[uMN];
+      f[uMN] = u[uMN] * vn + pgf;
+      f[uMT1] = vn * u[uMT1];
+      f[uMT2] = vn * u[uMT2];
+      f[uERG] = vn * (u[uERG] + pgf);
+      return;
+    }
+#endif
     double pg = (g - 1.) * (u[uERG] - (u[uMN] * u[uMN] + u[uMT1] * u[uMT1] + u[uMT2] * u[uMT2]) * 0.5 / u[uRHO]);
     f[uRHO] = u[uMN];
     f[uMN] = u[uMN] * u[uMN] / u[uRHO] + pg;

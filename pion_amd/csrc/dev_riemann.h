@@ -64,7 +64,7 @@ struct Flux {
   {
     double meanp[5], ul[5], ur[5], eval[5], strength[5], udiff[5];
     double rl = psqrt(left[qRO]), rr = psqrt(right[qRO]), lH = E::Enthalpy(left, g), rH = E::Enthalpy(right, g),
-           denom = 1.0 / (rl + rr);
+           denom = prcp(rl + rr);
     meanp[qRO] = rl * rr;
     meanp[qVN] = (rl * left[qVN] + rr * right[qVN]) * denom;
     meanp[qVT1] = (rl * left[qVT1] + rr * right[qVT1]) * denom;
@@ -101,9 +101,15 @@ struct Flux {
     strength[2] = udiff[uMT1] - meanp[qVT1] * udiff[uRHO];
     strength[3] = udiff[uMT2] - meanp[qVT2] * udiff[uRHO];
     double u5bar = udiff[uERG] - strength[2] * meanp[qVT1] - strength[3] * meanp[qVT2];
+#ifdef PION_FAST_MATH
+    const double ia = frcp(a_mean);
+    strength[1] = (udiff[uRHO] * (HH - meanp[qVN] * meanp[qVN]) + meanp[qVN] * udiff[uMN] - u5bar) * (g - 1.0) * ia * ia;
+    strength[0] = 0.5 * (udiff[uRHO] * (meanp[qVN] + a_mean) - udiff[uMN] - a_mean * strength[1]) * ia;
+#else
     strength[1] = (udiff[uRHO] * (HH - meanp[qVN] * meanp[qVN]) + meanp[qVN] * udiff[uMN] - u5bar) * (g - 1.0) /
                   a_mean / a_mean;
     strength[0] = 0.5 * (udiff[uRHO] * (meanp[qVN] + a_mean) - udiff[uMN] - a_mean * strength[1]) / a_mean;
+#endif
     strength[4] = udiff[uRHO] - strength[0] - strength[1];
     double fr[5];
     E::euler_UtoFlux(ul, out_flux, g);
