@@ -696,11 +696,14 @@ struct Flux {
   //     F = F_K + [region>=1] S_K (U*_K - U_K) + [region==2] S*_K (U**_K - U*_K),
   // which is the reference's expression regrouped (exact in real arithmetic, differs by rounding).
   // Reciprocals are shared and a^2 = gamma p/rho is used where the strict form squares sqrt(a^2).
-  static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar)
+  static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar,
+                        double *out_pstar)
   {
     const double BX = 0.5 * (Pl[qBN] + Pr[qBN]);
     const double BX2 = BX * BX;
-    const double irl = frcp(Pl[qRO]), irr = frcp(Pr[qRO]);
+    // (pairs of reciprocals from one: 1/a = b/(ab), 1/b = a/(ab))
+    const double irlr = frcp(Pl[qRO] * Pr[qRO]);
+    const double irl = irlr * Pr[qRO], irr = irlr * Pl[qRO];
     // HLLD_signal_speeds with B_n := BX
     double cfm;
     {
@@ -720,7 +723,8 @@ struct Flux {
     const double SM = (rsr * Pr[qVN] - rsl * Pl[qVN] - ptr + ptl) * itemp;
     const double pts = (rsr * ptl - rsl * ptr + rsl * rsr * (Pr[qVN] - Pl[qVN])) * itemp;
     const double sl_sm = SL - SM, sr_sm = SR - SM;
-    const double isl_sm = frcp(sl_sm), isr_sm = frcp(sr_sm);   // (one of them is reused for U*_K below)
+    const double islr_sm = frcp(sl_sm * sr_sm);
+    const double isl_sm = islr_sm * sr_sm, isr_sm = islr_sm * sl_sm;   // (one of them is reused for U*_K below)
     const double rosl = rsl * isl_sm, rosr = rsr * isr_sm;
     // tangential velocity and field behind the fast waves, both sides (the ** state needs both)
     double vys_l = Pl[qVT1], vzs_l = Pl[qVT2], bys_l = 0.0, bzs_l = 0.0;
@@ -821,6 +825,20 @@ struct Flux {
     out_ustar[uBT1] = w2 ? Uss[uBT1] : (w1 ? Us[uBT1] : UK[uBT1]);
     out_ustar[uBT2] = w2 ? Uss[uBT2] : (w1 ? Us[uBT2] : UK[uBT2]);
     out_ustar[uERG] = w2 ? Uss[uERG] : (w1 ? Us[uERG] : UK[uERG]);
+    // the same state in primitive variables, taken from the wave-fan quantities instead of dividing the
+    // momenta by rho again (eqns_mhd_ideal::UtoP of out_ustar up to rounding)
+    out_pstar[qRO] = out_ustar[uRHO];
+    out_pstar[qVN] = w1 ? SM : PK[qVN];
+    out_pstar[qVT1] = w2 ? vy_ss : (w1 ? vysK : PK[qVT1]);
+    out_pstar[qVT2] = w2 ? vz_ss : (w1 ? vzsK : PK[qVT2]);
+    out_pstar[qBN] = out_ustar[uBN];
+    out_pstar[qBT1] = out_ustar[uBT1];
+    out_pstar[qBT2] = out_ustar[uBT2];
+    out_pstar[qPG] = (g - 1) * (out_ustar[uERG] -
+                                out_pstar[qRO] * (out_pstar[qVN] * out_pstar[qVN] + out_pstar[qVT1] * out_pstar[qVT1] +
+                                                  out_pstar[qVT2] * out_pstar[qVT2]) * 0.5 -
+                                (out_pstar[qBN] * out_pstar[qBN] + out_pstar[qBT1] * out_pstar[qBT1] +
+                                 out_pstar[qBT2] * out_pstar[qBT2]) * 0.5);
   }
 #else
   static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar)
@@ -1382,7 +1400,18 @@ struct Flux {
       for (int v = 0; v < NV; v++) ustar[v] = 0.0;
       if constexpr (SOLVER == FLUX_RS_HLLD) {
         if (use_hll) hll_mhd(Pl, Pr, g, flux, ustar);
+#ifdef PION_FAST_MATH
+        else {
+          // fast build: HLLD hands back the resolved state in primitive variables as well
+#pragma unroll
+          for (int v = 8; v < NV; v++) pstar[v] = 0.0;
+          hlld(Pl, Pr, g, flux, ustar, pstar);
+          E::check_pressure(pstar, c.min_temp, c.mp, err);
+          return;
+        }
+#else
         else hlld(Pl, Pr, g, flux, ustar);
+#endif
       }
       else {
         hll_mhd(Pl, Pr, g, flux, ustar);
