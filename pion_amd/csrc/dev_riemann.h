@@ -750,9 +750,14 @@ struct Flux {
       bys_r = Pr[qBT1] * q2;
       bzs_r = Pr[qBT2] * q2;
     }
-    double sql, sqr, isql, isqr;   // rho*_K > 0 (S_K - v_K and S_K - S_M have the same sign)
-    sqrt_rsqrt_pos(rosl, sql, isql);
-    sqrt_rsqrt_pos(rosr, sqr, isqr);
+    // rho*_K > 0 when S_K - v_K and S_K - S_M have the same sign.  With a large jump of B_n (ideal MHD
+    // without GLM: each side's total pressure carries its own B_n) S_M can leave [S_L, S_R] and make the
+    // star density of the side that is NOT selected negative; the reference builds that side's NaN state
+    // and never uses it, here it would enter as 0 x NaN, so the argument of the root is kept positive
+    // (v_max also drops a NaN).
+    double sql, sqr, isql, isqr;
+    sqrt_rsqrt_pos(fmx(rosl, PION_TINYVALUE), sql, isql);
+    sqrt_rsqrt_pos(fmx(rosr, PION_TINYVALUE), sqr, isqr);
     const double aBX = fabs(BX);
     const double SsL = SM - aBX * isql, SsR = SM + aBX * isqr;
     // Alfven-averaged state
