@@ -82,6 +82,42 @@ def cpu_baseline(n, eqntype, solver, budget_s=12.0):
     return out
 
 
+def parity_build_run(args, cfg, device, dt_lim, steps=3, warmup=1):
+    """`steps` steps of the benchmark workload with the bit-parity kernels (strict_fp = 1)"""
+    cfg.strict_fp = 1
+    sim = lib.GpuSim(cfg, device)
+    try:
+        if args.workload == "m1":
+            P = problems.fill_mhd_blastwave(cfg)
+        elif args.workload == "m2":
+            P = problems.fill_hd_blast_octant(cfg, args.n / 32.0)
+        else:
+            from pion_amd import cooling
+            P, (widx, wst), dt_lim = problems.fill_wind3d(cfg, args.n)
+            sim.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
+            sim.set_wind_cells(widx, wst)
+        sc = driver.SimControl(sim, cfg)
+        sc.first_step_dt_limit = dt_lim
+        sc.init(P)
+        del P
+        for _ in range(warmup):
+            sc.calculate_timestep()
+            sc.advance_time()
+        sim.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sc.calculate_timestep()
+            sc.advance_time()
+        sim.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        sim.close()
+    ncell = cfg.ng[0] * cfg.ng[1] * cfg.ng[2]
+    return {"value": ncell * steps / el / 1e6, "unit": "Mcell-updates/s", "ms_per_step": el / steps * 1e3,
+            "steps": steps, "warmup": warmup,
+            "fp_mode": "strict (-ffp-contract=off, reference operation order; bit-identical to the oracle)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +127,7 @@ def main():
     ap.add_argument("--eqn", default="glm", choices=["glm", "mhd"])
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-parity kernels (no FMA contraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-build", action="store_true", help="skip the strict-build throughput run")
     ap.add_argument("--cpu-n", type=int, default=64)
     ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3"],
                     help="m1 (default, the headline): MHD blast; m2: 3-D Euler Roe-CV octant Sedov blast (SURVEY 8d); "
@@ -111,10 +148,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run) BEFORE anything in this process touches the GPU, relay rank 0's JSON
+        # line (the children inherit stdout) and exit with the launcher's code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+              [("--grid" if a == "--n" else a) for a in sys.argv[1:]]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
     eq = abi.EQGLM if args.eqn == "glm" else abi.EQMHD
     solver = abi.FLUX_RS_HLLD
 
@@ -270,8 +320,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "m1":
             out["cpu_baseline"] = cpu_baseline(args.cpu_n, eq, solver)
+        if world == 1 and not loopback and not args.strict and not args.no_parity_build:
+            # the same workload through the PARITY build (strict_fp=1: -ffp-contract=off, the reference's
+            # operation order, bit-identical to the oracle): its throughput beside the headline
+            sim.close()
+            sim = None
+            out["parity_build"] = parity_build_run(args, cfg, local_rank, dt_lim)
         print(json.dumps(out))
-    sim.close()
+    if sim is not None:
+        sim.close()
     if world > 1 or loopback:
         dist.destroy_process_group()
 

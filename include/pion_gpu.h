@@ -120,7 +120,7 @@ typedef struct pion_gpu_config {
   int bc_type[6];            /* PION_BC_* for XN,XP,YN,YP,ZN,ZP (0 on unused axes) */
   int bc_dmach2;             /* 1: internal DMR2 boundary active */
   int cooling;               /* EP.cooling (PION_COOL_*), 0 = no microphysics object */
-  int mp_timestep_limit;     /* EP.MP_timestep_limit */
+  int mp_timestep_limit;     /* EP.MP_timestep_limit: 0 none; 1,2,3 cooling time; 4 none (recombination only); else EINVAL */
   int strict_fp;             /* 1: kernels built without FMA contraction (bit-parity build) */
 } pion_gpu_config;
 

@@ -367,6 +367,14 @@ int check_errword(Handle *h)
   return 0;
 }
 
+// get_mp_timescales_no_radiation (calc_timestep.cpp:445-459): EP.MP_timestep_limit 1, 2, 3 ask
+// mp_only_cooling::timescales for the cooling time (tc = true); 4 (recombination time only) gets 1e99
+// from it (mp_only_cooling.cpp:338), i.e. no limit; anything else is fatal there (EINVAL in create).
+static inline bool mp_dt_limited(const pion_gpu_config &cfg)
+{
+  return cfg.cooling != 0 && cfg.mp_timestep_limit >= 1 && cfg.mp_timestep_limit <= 3;
+}
+
 // device scratch of the test seams: freed on every return path
 struct DevBuf {
   double *p = nullptr;
@@ -403,6 +411,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   else if (!(cfg->solver == 0 || cfg->solver == 1 || cfg->solver == 4 || cfg->solver == 7 || cfg->solver == 8))
     return PION_GPU_EINVAL;
   if (cfg->cooling != 0 && cfg->cooling != PION_COOL_WSS09_CIE_LINE_HEAT_COOL) return PION_GPU_EINVAL;
+  if (cfg->mp_timestep_limit < 0 || cfg->mp_timestep_limit > 4) return PION_GPU_EINVAL;  // calc_timestep.cpp:457
 
   Handle *h = new Handle;
   h->cfg = *cfg;
@@ -907,7 +916,7 @@ int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
   a.nvar = h->cfg.nvar;
   a.gamma = h->cfg.gamma;
   a.cfl = h->cfg.cfl;
-  a.do_mp = (h->cfg.cooling != 0 && h->cfg.mp_timestep_limit != 0) ? 1 : 0;
+  a.do_mp = mp_dt_limited(h->cfg) ? 1 : 0;
   a.cool = h->cool;
   if (a.do_mp && !h->have_tables) {
     h->err = "cooling tables not set";
@@ -1078,7 +1087,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
                        && h->g.nbc[2] >= 2 && a.out == h->dP;
   a.dtres = nullptr;
   a.cfl = cfg.cfl;
-  a.dt_mp = (cfg.cooling != 0 && cfg.mp_timestep_limit != 0) ? 1 : 0;
+  a.dt_mp = mp_dt_limited(cfg) ? 1 : 0;
   h->dt_cached = false;
   if (fuse_dt) {
     if (first)

@@ -2,7 +2,9 @@
 #include "sim_control_gpu.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <stdexcept>
+#include <string>
 
 namespace pion_host {
 
@@ -99,6 +101,7 @@ int sim_control_gpu::Time_Int(int nsteps)
 }  // namespace pion_host
 
 // ---- C view of the adapter (used by tests/bench through ctypes) -------------------------------
+static thread_local std::string g_last_exception;
 extern "C" {
 int pion_host_sim_create(const pion_gpu_config *cfg, int device, void **sim)
 {
@@ -106,8 +109,9 @@ int pion_host_sim_create(const pion_gpu_config *cfg, int device, void **sim)
     *sim = new pion_host::sim_control_gpu(*cfg, device);
     return 0;
   }
-  catch (const std::exception &) {
+  catch (const std::exception &e) {
     *sim = nullptr;
+    g_last_exception = e.what();
     return PION_GPU_EDEVICE;
   }
 }
@@ -129,9 +133,22 @@ int pion_host_sim_time_int(void *s, int nsteps, double *simtime, double *last_dt
     *last_dt = c->T.last_dt;
     return n;
   }
-  catch (const std::exception &) {
+  catch (const std::exception &e) {
+    g_last_exception = e.what();   // the reference prints the rep.error text before exit(1); keep it readable
     return -1;
   }
+}
+// text of the last exception a pion_host_* call swallowed (empty if none), plus the handle's own error
+int pion_host_sim_last_error(void *s, char *buf, int len)
+{
+  if (!buf || len <= 0) return PION_GPU_EINVAL;
+  std::string m = g_last_exception;
+  if (s) {
+    const std::string h = static_cast<pion_host::sim_control_gpu *>(s)->last_error();
+    if (!h.empty()) m += (m.empty() ? "" : " | ") + h;
+  }
+  snprintf(buf, (size_t)len, "%s", m.c_str());
+  return 0;
 }
 int pion_host_sim_download(void *s, int which, double *P)
 {

@@ -1,0 +1,89 @@
+"""The full 62-cell x-tile path of the 3-D stage kernel against the ORACLE.
+
+Every other oracle-compared 3-D grid has nx <= 48, i.e. only the packed remainder wavefront of
+k_stage_rows runs.  Here nx = 70 (one full tile + an 8-cell remainder) and nx = 130 (two full tiles + a
+6-cell remainder), ny not a multiple of the rows per wavefront, and data with gradients across every
+tile seam.  Strict build: bit-exact.  Fast (benchmarked) build: cell-wise within 1e-11 of each
+variable's scale per step, on problems where the reference itself is well conditioned
+(tests/test_reference_conditioning.py)."""
+import numpy as np
+import pytest
+
+from pion_amd import abi, driver, problems
+from test_gpu_parity import run_pair, _gpu, _cpu
+
+pytestmark = pytest.mark.gpu
+
+GRIDS = [[130, 9, 20], [70, 14, 12]]
+
+
+def _case(name, ng, strict):
+    if name == "glm_hlld":
+        return problems.mhd_blast_generic(ng, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=strict)
+    if name == "mhd_hlld":
+        return problems.mhd_blast_generic(ng, abi.EQMHD, abi.FLUX_RS_HLLD, strict_fp=strict)
+    if name == "glm_hlld_tr":
+        return problems.mhd_blast_generic(ng, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=strict, ntracer=1)
+    if name == "hd_roe":
+        return problems.hd_blast_box(ng, solver=abi.FLUX_RSroe, strict_fp=strict)
+    if name == "hd_fvs_tr":
+        return problems.hd_blast_box(ng, solver=abi.FLUX_FVS, ntracer=1, strict_fp=strict)
+    raise KeyError(name)
+
+
+CASES = ["glm_hlld", "mhd_hlld", "glm_hlld_tr", "hd_roe", "hd_fvs_tr"]
+
+
+@pytest.mark.parametrize("ng", GRIDS, ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("case", CASES)
+def test_full_xtile_strict_bitexact_vs_oracle(case, ng):
+    cfg, P = _case(case, ng, 1)
+    run_pair(cfg, P, 2)
+
+
+@pytest.mark.parametrize("ng", GRIDS, ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("case", CASES)
+def test_full_xtile_fast_vs_oracle(case, ng):
+    """the benchmarked build, cell by cell against the oracle: <= 1e-11 of each variable's scale per step"""
+    cfg, P = _case(case, ng, 0)
+    run_pair(cfg, P, 3, strict=False, tol=3e-11)
+
+
+def _norms(a, b, refvec):
+    """per-variable L1 / L2 / max norms of a-b over the on-grid cells, relative to refvec
+    (the norms of analysis/silocompare/silocompare.cpp:371-430)"""
+    nv = a.shape[0]
+    d = np.abs(a - b).reshape(nv, -1)
+    rv = np.asarray(refvec[:nv]).reshape(-1, 1)
+    return (d.mean(axis=1) / rv[:, 0], np.sqrt((d * d).mean(axis=1)) / rv[:, 0], d.max(axis=1) / rv[:, 0])
+
+
+@pytest.mark.parametrize("eq", [abi.EQGLM, abi.EQMHD])
+def test_fast_build_vs_oracle_blast_64cubed_10_steps(eq):
+    """SURVEY 8(d) gate for the benchmarked build: per-variable L1 and L2 <= 1e-10 x refvec against the
+    oracle after ten steps of the (well-conditioned) MHD blast on 64^3 -- two full x tiles are not needed
+    here (nx = 64 = one full tile + 2), the shock crosses several cells."""
+    cfg, P = problems.mhd_blast_generic([64, 64, 64], eq, abi.FLUX_RS_HLLD, strict_fp=0)
+    nb = cfg.nbc
+    with _gpu(cfg) as g, _cpu(cfg) as o:
+        sg, so = driver.SimControl(g, cfg), driver.SimControl(o, cfg)
+        sg.init(P)
+        so.init(P)
+        for _ in range(10):
+            dg, do = sg.calculate_timestep(), so.calculate_timestep()
+            assert abs(dg - do) <= 1e-11 * do
+            so.dt = sg.dt
+            sg.advance_time()
+            so.advance_time()
+        a = g.download(0)[:, nb:-nb, nb:-nb, nb:-nb]
+        b = o.download(0)[:, nb:-nb, nb:-nb, nb:-nb]
+    refvec = [cfg.refvec[v] for v in range(cfg.nvar)]
+    l1, l2, mx = _norms(a, b, refvec)
+    assert l1.max() <= 1e-10 and l2.max() <= 1e-10, (l1, l2, mx)
+    assert mx.max() <= 1e-8, mx
+
+
+def test_strict_build_bitexact_blast_64cubed():
+    """the same problem, parity build: bit for bit after three steps (oracle cost ~2 s/step)"""
+    cfg, P = problems.mhd_blast_generic([64, 64, 64], abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
+    run_pair(cfg, P, 3)
