@@ -14,6 +14,8 @@
 namespace pion {
 
 #define PION_MAX_NTR 2
+// LDS a workgroup of k_stage_rows2 may use so that two fit a CU (160 KiB)
+#define PION_ROWS2_LDS_BYTES (80 * 1024)
 #define PION_COOL_NT_MAX 256
 
 struct GridDesc {
@@ -52,7 +54,9 @@ struct StageArgs {
   double dt;          // stage dt (= FV_dt)
   double glm_damp;    // exp(-FV_dt*chyp*cr), evaluated on the host
   double max_temp;    // EP.MaxTemperature
-  int use_march;      // 2: k_stage_rows, 1: k_stage_march (3-D, nbc>=2), 0: k_stage (cell per thread)
+  int use_march;      // 3: k_stage_rows2 (production), 2: k_stage_rows, 1: k_stage_march (3-D, nbc>=2), 0: k_stage (cell per thread)
+  int zslope_lds;     // k_stage_rows2: carry the z slope in LDS (else rebuild it from plane k-1)
+  double *dE;         // k_stage_rows2: cooling source PtoU(p_new)[ERG]-PtoU(P)[ERG] per cell from k_cooling_dE (or null)
   int zchunk;         // planes per wavefront in the marching kernels
   int rows;           // y-rows per wavefront in k_stage_rows
   int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows; others: whole grid)
@@ -109,6 +113,8 @@ struct CoolTestArgs {
 #define PION_DECLARE_FP(NS)                                        \
   namespace NS {                                                   \
   int launch_stage(const StageArgs &a, hipStream_t s);             \
+  int launch_cooling_dE(const StageArgs &a, hipStream_t s);        \
+  int stage_rows2_rows(int eq, int ntr, int zslope_lds, int want); \
   int launch_prepass(const PrepassArgs &a, hipStream_t s);         \
   int launch_dt(const DtArgs &a, hipStream_t s);                   \
   int launch_flux_test(const FluxTestArgs &a, hipStream_t s);      \

@@ -523,10 +523,61 @@ __global__ __launch_bounds__(256) void k_flux_test(const FluxTestArgs a)
 
 #include "stage_march.h"
 #include "stage_rows.h"
+#include "stage_rows2.h"
+
+// ---------------------------------------------------------------------------
+// cooling source term, one thread per on-grid cell of the planes a stage launch updates:
+// calc_noRT_microphysics_dU (time_integrator.cpp:438-489) -> mp_only_cooling::TimeUpdateMP.  Only the
+// energy component of dU changes, so the kernel leaves dE = PtoU(p_new)[ERG] - PtoU(P)[ERG] (the same two
+// PtoU evaluations the reference subtracts) for k_stage_rows2 to start its dU from.  The adaptive
+// Cash-Karp loop diverges from cell to cell: here it runs at full occupancy, outside the stage kernel.
+// ---------------------------------------------------------------------------
+template <int EQ, int NTR>
+__global__ __launch_bounds__(256) void k_cooling_dE(const StageArgs a)
+{
+  typedef Eqn<EQ, NTR> E;
+  constexpr int NV = E::NV;
+  const unsigned gx = (a.g.ng[0] + 63) / 64, gy = (a.g.ng[1] + 3) / 4;
+  const unsigned np1 = (unsigned)(a.kz1 - a.kz0), np2 = (a.kz3 > a.kz2) ? (unsigned)(a.kz3 - a.kz2) : 0u;
+  const unsigned ntile = gx * gy * (np1 + np2);
+  const unsigned t = (unsigned)xcd_tile(blockIdx.x, ntile);
+  if (t >= ntile) return;
+  const int ix = (int)((t % gx) * 64 + (threadIdx.x & 63));
+  const int iy = (int)(((t / gx) % gy) * 4 + (threadIdx.x >> 6));
+  const unsigned pz = t / (gx * gy);
+  const int iz = (pz < np1) ? a.kz0 + (int)pz : a.kz2 + (int)(pz - np1);
+  if (ix >= a.g.ng[0] || iy >= a.g.ng[1]) return;
+  const long nc = a.g.ncell;
+  const long c = (long)(ix + a.g.nbc[0]) + a.g.sy * (iy + a.g.nbc[1]) + a.g.sz * (iz + a.g.nbc[2]);
+  double dE = 0.0;
+  if (a.flags[c] & 4 /*ISDOMAIN*/) {
+    const double g = a.fc.gamma;
+    int err = 0;
+    double P0[NV], pn[NV], ui[NV], uf[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) pn[v] = P0[v] = a.Pc[v * nc + c];
+    pn[qPG] = Cooling::time_update(a.cool, P0[qRO], P0[qPG], a.dt, g, err);
+    E::PtoU(P0, ui, g);
+    E::PtoU(pn, uf, g);
+    dE = uf[uERG] - ui[uERG];
+    if (err) atomicOr(a.errword, err);
+  }
+  a.dE[c] = dE;
+}
+template <int EQ, int NTR>
+static int cooling_go(const StageArgs &a, hipStream_t s)
+{
+  const unsigned gx = (a.g.ng[0] + 63) / 64, gy = (a.g.ng[1] + 3) / 4;
+  const unsigned np = (unsigned)(a.kz1 - a.kz0) + ((a.kz3 > a.kz2) ? (unsigned)(a.kz3 - a.kz2) : 0u);
+  const unsigned ntile = gx * gy * np;
+  hipLaunchKernelGGL((k_cooling_dE<EQ, NTR>), dim3(((ntile + 7) / 8) * 8), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
 
 template <int EQ, int NTR, int SOLVER>
 static int stage_go(const StageArgs &a, hipStream_t s)
 {
+  if (a.use_march == 3 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_rows2_go<EQ, NTR, SOLVER>(a, s);
   if (a.use_march == 2 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_rows_go<EQ, NTR, SOLVER>(a, s);
   if (a.use_march == 1 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_march_go<EQ, NTR, SOLVER>(a, s);
   const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
@@ -580,12 +631,28 @@ static int flux_go(const FluxTestArgs &a, hipStream_t s)
 #define PION_CAT2(a, b) a##b
 #define PION_CAT(a, b) PION_CAT2(a, b)
 
+#ifdef PION_PROBE
+// register / ISA probe builds (profiles/tools/probe_regs.sh): instantiate the production instances only
+int PION_CAT(launch_stage_, PION_SUFFIX)(const StageArgs &a, hipStream_t s)
+{
+  return stage_rows2_go<PION_EQ, 0, (PION_EQSEL == 1 ? 4 : 7)>(a, s);
+}
+#else
 int PION_CAT(launch_stage_, PION_SUFFIX)(const StageArgs &a, hipStream_t s)
 {
   switch (a.ntracer) {
     case 0: PION_CASES(stage_go, PION_EQ, 0, a, s)
     case 1: PION_CASES(stage_go, PION_EQ, 1, a, s)
     case 2: PION_CASES(stage_go, PION_EQ, 2, a, s)
+    default: return -1;
+  }
+}
+int PION_CAT(launch_cooling_dE_, PION_SUFFIX)(const StageArgs &a, hipStream_t s)
+{
+  switch (a.ntracer) {
+    case 0: return cooling_go<PION_EQ, 0>(a, s);
+    case 1: return cooling_go<PION_EQ, 1>(a, s);
+    case 2: return cooling_go<PION_EQ, 2>(a, s);
     default: return -1;
   }
 }
@@ -598,12 +665,16 @@ int PION_CAT(launch_flux_test_, PION_SUFFIX)(const FluxTestArgs &a, hipStream_t 
     default: return -1;
   }
 }
+#endif  // PION_PROBE
 
 #else  // PION_EQSEL == 0 : shared kernels -----------------------------------
 
 int launch_stage_hd(const StageArgs &a, hipStream_t s);
 int launch_stage_mhd(const StageArgs &a, hipStream_t s);
 int launch_stage_glm(const StageArgs &a, hipStream_t s);
+int launch_cooling_dE_hd(const StageArgs &a, hipStream_t s);
+int launch_cooling_dE_mhd(const StageArgs &a, hipStream_t s);
+int launch_cooling_dE_glm(const StageArgs &a, hipStream_t s);
 int launch_flux_test_hd(const FluxTestArgs &a, hipStream_t s);
 int launch_flux_test_mhd(const FluxTestArgs &a, hipStream_t s);
 int launch_flux_test_glm(const FluxTestArgs &a, hipStream_t s);
@@ -614,6 +685,23 @@ int launch_stage(const StageArgs &a, hipStream_t s)
   if (a.eqntype == EQMHD) return launch_stage_mhd(a, s);
   if (a.eqntype == EQGLM) return launch_stage_glm(a, s);
   return -1;
+}
+int launch_cooling_dE(const StageArgs &a, hipStream_t s)
+{
+  if (a.eqntype == EQEUL) return launch_cooling_dE_hd(a, s);
+  if (a.eqntype == EQMHD) return launch_cooling_dE_mhd(a, s);
+  if (a.eqntype == EQGLM) return launch_cooling_dE_glm(a, s);
+  return -1;
+}
+// rows per wavefront k_stage_rows2 will use (LDS budget), for the host's launch cost model
+int stage_rows2_rows(int eq, int ntr, int zslope_lds, int want)
+{
+  const int nv = ((eq == EQEUL) ? 5 : ((eq == EQMHD) ? 8 : 9)) + ntr;
+  const int nz = zslope_lds ? 2 * nv : nv;
+  int r = (int)(PION_ROWS2_LDS_BYTES / (sizeof(double) * 4 * nz * 64));
+  if (r > 8) r = 8;
+  if (want < r) r = want;
+  return r < 1 ? 1 : r;
 }
 int launch_flux_test(const FluxTestArgs &a, hipStream_t s)
 {

@@ -278,7 +278,9 @@ struct Handle {
   bool timing = false;
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
-  int use_march = 2, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
+  int use_march = 3, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
+  int zslope_lds = 0;     // k_stage_rows2: carry the z slope in LDS (PION_ZSLOPE_LDS=1) instead of rebuilding it
+  double *ddE = nullptr;  // cooling source per cell (k_cooling_dE -> k_stage_rows2)
   bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
   bool fuse_bc = true;    // PION_FUSE_BC=0: periodic faces one launch per face (A/B)
 };
@@ -416,7 +418,8 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   Handle *h = new Handle;
   h->cfg = *cfg;
   if (const char *e = getenv("PION_STAGE_KERNEL"))
-    h->use_march = (strcmp(e, "cell") == 0) ? 0 : ((strcmp(e, "march") == 0) ? 1 : 2);
+    h->use_march = (strcmp(e, "cell") == 0) ? 0 : ((strcmp(e, "march") == 0) ? 1 : ((strcmp(e, "rows1") == 0) ? 2 : 3));
+  if (const char *e = getenv("PION_ZSLOPE_LDS")) h->zslope_lds = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
   if (const char *e = getenv("PION_ROWS")) h->rows = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
@@ -477,6 +480,10 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (cfg->eqntype != PION_EQEUL && cfg->solver == PION_FLUX_RS_HLLD) {
     HCHECK(h, hipMalloc(&h->dhll, g.ncell));
     HCHECK(h, hipMemset(h->dhll, 0, g.ncell));
+  }
+  if (cfg->cooling != 0) {
+    HCHECK(h, hipMalloc(&h->ddE, sizeof(double) * g.ncell));
+    HCHECK(h, hipMemset(h->ddE, 0, sizeof(double) * g.ncell));
   }
   if (cfg->artvisc == PION_AV_HCORRECTION || cfg->artvisc == PION_AV_HCORR_FKJ98) {
     HCHECK(h, hipMalloc(&h->deta, sizeof(double) * cfg->ndim * g.ncell));
@@ -596,6 +603,7 @@ void pion_gpu_destroy(void *handle)
   }
   hipFree(h->dflags);
   hipFree(h->dhll);
+  hipFree(h->ddE);
   hipFree(h->deta);
   hipFree(h->dsphvol);
   hipFree(h->derr);
@@ -954,7 +962,7 @@ int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr)
 // part (the nbc on-grid planes next to each z face) waits for the unpacked halo.
 static bool stage_can_split(const Handle *h)
 {
-  return h->use_march == 2 && h->g.ndim == 3 && h->g.nbc[2] >= 2 && !h->deta
+  return h->use_march >= 2 && h->g.ndim == 3 && h->g.nbc[2] >= 2 && !h->deta
          && h->g.ng[2] > 2 * h->g.nbc[2] && !(h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1);
 }
 
@@ -1052,21 +1060,28 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.kz1 = kz1;
   a.kz2 = kz2;
   a.kz3 = (kz3 > kz2) ? kz3 : kz2;
+  a.zslope_lds = h->zslope_lds;
+  a.dE = nullptr;
+  if (a.use_march == 3 && h->g.ndim == 3)
+    a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows)
+                           : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows);
   if (a.zchunk <= 0) {
-    // Planes per wavefront.  Every wavefront takes about (zchunk + 1 priming plane) plane visits, one
-    // wavefront runs per SIMD, and a launch proceeds in rounds of (4 x CUs) equal wavefronts, so its cost
-    // is ceil(wavefronts / slots) x (zchunk + 1): pick the chunk that minimises it (512^3 on 256 CUs:
-    // 32 planes, 17 rounds of 33 visits, instead of 64 planes, 9 rounds of 65: measured 22.9 -> 21.8 ms).
+    // Planes per wavefront.  Every wavefront takes about (zchunk + 1 priming plane) plane visits, a CU holds
+    // `slots` wavefronts at a time (k_stage_rows: 4, k_stage_rows2: 8), and a launch proceeds in rounds of
+    // equal wavefronts, so its cost is ceil(wavefronts / slots) x (zchunk + 1): pick the chunk that
+    // minimises it.
     const int nv = cfg.nvar;
     int rows = a.rows;
-    const int rmax = (int)((160 * 1024) / (sizeof(double) * 4 * (2 * nv) * 64));
-    if (rows > rmax) rows = rmax;
+    if (a.use_march != 3) {
+      const int rmax = (int)((160 * 1024) / (sizeof(double) * 4 * (2 * nv) * 64));
+      if (rows > rmax) rows = rmax;
+    }
     if (rows < 1) rows = 1;
     const int nyg = (h->g.ng[1] + rows - 1) / rows;
     const int ntx_full = h->g.ng[0] / 62, rem = h->g.ng[0] - ntx_full * 62;
     const int spw = (rem > 0) ? 64 / (rem + 2) : 0;
     const long per_chunk = (long)ntx_full * nyg + ((rem > 0) ? (nyg + spw - 1) / spw : 0);
-    const long slots = 4L * (h->ncu > 0 ? h->ncu : 256);
+    const long slots = ((a.use_march == 3) ? 8L : 4L) * (h->ncu > 0 ? h->ncu : 256);
     const int np = kz1 - kz0;
     long best_cost = -1;
     a.zchunk = 8;
@@ -1081,9 +1096,20 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
       }
     }
   }
+  if (cfg.cooling != 0 && a.use_march == 3 && h->g.ndim == 3 && h->g.nbc[2] >= 2) {
+    // calc_noRT_microphysics_dU as its own launch (thread per cell, full occupancy): dE per cell
+    a.dE = h->ddE;
+    time_begin(h, 1);
+    rc = cfg.strict_fp ? fp_strict::launch_cooling_dE(a, h->stream) : fp_fast::launch_cooling_dE(a, h->stream);
+    time_end(h, 1);
+    if (rc != 0) {
+      h->err = "cooling kernel launch failed";
+      return PION_GPU_EDEVICE;
+    }
+  }
   // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
   // (second-order stages only: the first-order instances of k_stage_rows carry no reduction code)
-  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march == 2 && h->g.ndim == 3
+  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march >= 2 && h->g.ndim == 3
                        && h->g.nbc[2] >= 2 && a.out == h->dP;
   a.dtres = nullptr;
   a.cfl = cfg.cfl;

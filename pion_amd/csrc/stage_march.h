@@ -105,16 +105,15 @@ PDEV void apply_axis(double *d, const double *q0, const double bnm, const double
   }
 }
 
-// CellAdvanceTime + temperature clamp + store (see k_stage)
+// CellAdvanceTime + temperature clamp (see k_stage): P0 + dU -> Pf
 template <int EQ, int NTR>
-PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, const double *dU, int &err,
-                           double *Pfout = nullptr, const bool no_mp = false)
+PDEV void cell_update(const StageArgs &a, const double *P0, const double *dU, int &err, double *Pf,
+                      const bool no_mp = false)
 {
   typedef Eqn<EQ, NTR> E;
   constexpr int NV = E::NV;
   const double g = a.fc.gamma;
-  const long nc = a.g.ncell;
-  double u1[NV], Pf[NV];
+  double u1[NV];
   MPd mp = a.fc.mp;
   if (no_mp) mp.present = false;  // compile-time constant in the PLAIN instances of k_stage_rows
   if (mp.present) {
@@ -134,6 +133,16 @@ PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, 
     const double T = Pf[qPG] * mp.Mu_tot_over_kB / Pf[qRO];
     if (T > a.max_temp) Pf[qPG] = Pf[qRO] * a.max_temp / mp.Mu_tot_over_kB;
   }
+}
+// ... and store
+template <int EQ, int NTR>
+PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, const double *dU, int &err,
+                           double *Pfout = nullptr, const bool no_mp = false)
+{
+  constexpr int NV = Eqn<EQ, NTR>::NV;
+  const long nc = a.g.ncell;
+  double Pf[NV];
+  cell_update<EQ, NTR>(a, P0, dU, err, Pf, no_mp);
 #pragma unroll
   for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v];
   if (Pfout) {

@@ -1,0 +1,508 @@
+// stage_rows2.h -- k_stage_rows2: the 3-D production stage kernel, two wavefronts per SIMD.
+//
+// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after stage_march.h and stage_rows.h,
+// whose helpers load_rot / slope3 / apply_axis / cell_update_store / cell_dt / rows_tiling it reuses).
+//
+// Same decomposition as k_stage_rows (one wavefront per x-pencil of 64 lanes owning R consecutive
+// y-rows, marching along z; x fluxes shared by wavefront shuffles, the y flux and the next row's y slope
+// carried from row to row in registers, the z-carried state of every row in LDS) rebuilt around the
+// round-1 profile: that kernel needed 500 registers (one wavefront per SIMD), spent 22 % of its wave
+// cycles parked on s_waitcnt with nothing else to issue, and 10 % of its instructions copying between
+// VGPRs and AGPRs.  Here
+//   * the kernel is built for <= 256 registers (__launch_bounds__(256, 2): two workgroups of four
+//     wavefronts per CU, two wavefronts per SIMD), so a wavefront waiting on memory has a partner that
+//     issues;
+//   * nothing is prefetched into registers across a Riemann solve: what is live across the one inlined
+//     flux body is this row's state q0, its dU, and the y carry (flux + slope) -- 4 x NV doubles;
+//   * LDS per wavefront halves (80 KiB per workgroup): with ZSL the z slope and the lower z flux of every
+//     row are carried (R = 2 rows at nvar 9), without it only the flux is carried and the slope of the
+//     current plane is rebuilt from plane k-1 (R = 4 rows at nvar 9: 3.25 instead of 3.5 Riemann solves per
+//     cell, one more read of each plane, which comes from L2 / the Infinity Cache);
+//   * the first-order stage reads the start-of-step state from the stencil array (they are the same
+//     array in that stage), the cooling source arrives as one double per cell from k_cooling.
+// The arithmetic and its order are the reference's (the strict build stays bit-identical to the oracle).
+#ifndef PION_STAGE_ROWS2_H
+#define PION_STAGE_ROWS2_H
+
+// Addressing: every global access of the kernel is "uniform base + 32-bit per-lane byte offset"
+// (global_load ... v_off, s[base:base+1]): the variable, the neighbour shift along y / z and the array are
+// folded into the scalar base, the x neighbours into the instruction's immediate offset, and the one
+// per-lane quantity -- the cell -- is a single VGPR per row.  (With 64-bit per-lane addresses the compiler
+// hoists one VGPR pair per load site out of the task loop: ~80 registers, which do not exist here.)
+// Needs 8 * ncell < 2^32 (checked by the launcher; 512^3 with ghosts is 1.1e9).
+// (readfirstlane keeps the optimiser from re-associating base + offset into per-lane 64-bit arithmetic; on a
+// value that already lives in SGPRs it costs nothing.  The access is made through an address_space(1)
+// pointer so that it stays a global_ instruction after the integer round trip.)
+PDEV unsigned long long uni(const void *p)
+{
+  const unsigned long long x = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+PDEV double ldu(const char *ubase, const unsigned off)
+{
+  typedef const __attribute__((address_space(1))) char *gc;
+  typedef const __attribute__((address_space(1))) double *gp;
+  return *(gp)((gc)uni(ubase) + off);
+}
+PDEV unsigned ldub(const char *ubase, const unsigned off)
+{
+  typedef const __attribute__((address_space(1))) unsigned char *gp;
+  return *((gp)uni(ubase) + off);
+}
+PDEV void stu(char *ubase, const unsigned off, const double x)
+{
+  typedef __attribute__((address_space(1))) char *gc;
+  typedef __attribute__((address_space(1))) double *gp;
+  *(gp)((gc)uni(ubase) + off) = x;
+}
+// an SGPR zero the optimiser cannot see through: added to an array base inside a task it keeps the
+// (loop-invariant) scalar address arithmetic of that task from being hoisted out of the row / plane loops,
+// where its ~70 base pairs would have to be spilled (SGPR spills cost VALU lane moves)
+PDEV unsigned opaque_zero()
+{
+  unsigned z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return z;
+}
+// sweep-frame state of the cell at uniform byte shift `sh` from the lane's cell
+template <int NV, bool MHD>
+PDEV void load_rot2(const char *Sb, const long ncb, const int ax, const long sh, const unsigned off, double *q)
+{
+#pragma unroll
+  for (int s = 0; s < NV; s++) q[s] = ldu(Sb + (long)rotvar<MHD>(ax, s) * ncb + sh, off);
+}
+
+template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN, bool ZSL>
+__global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
+{
+  typedef Eqn<EQ, NTR> E;
+  typedef Flux<EQ, NTR, SOLVER> FX;
+  constexpr int NV = E::NV;
+  constexpr bool MHD = E::MHD;
+  constexpr int NZ = ZSL ? 2 * NV : NV;   // LDS slots per row: [z slope,] lower z flux
+  extern __shared__ double lds[];
+
+  const int R = a.rows;
+  const RowsTiling tl = rows_tiling(a);
+  const int nyg = tl.nyg;
+  const int nzc1 = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
+  const int nzc = nzc1 + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;   // chunks of both strips
+  const long ntiles = (long)tl.per_chunk * nzc;
+  // the wavefront number is uniform: say so, and the tile / row / plane loops run on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
+  if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
+  const int cz = (int)(tile / tl.per_chunk), tt = (int)(tile % tl.per_chunk);
+  const int lane = threadIdx.x & 63;
+  int ix, jg, jg_first;   // jg: this LANE's row group; jg_first: the wavefront's first (uniform)
+  bool writer;
+  if (tt < tl.nfull) {
+    const int tx = tt % tl.ntx_full;
+    jg = jg_first = tt / tl.ntx_full;
+    ix = tx * PION_MARCH_XT - 1 + lane;
+    writer = (lane >= 1 && lane <= PION_MARCH_XT && ix < a.g.ng[0]);
+  }
+  else {
+    const int seg = lane / (tl.rem + 2), pos = lane % (tl.rem + 2);
+    jg_first = (tt - tl.nfull) * tl.spw;
+    jg = jg_first + seg;
+    ix = tl.ntx_full * PION_MARCH_XT - 1 + pos;
+    writer = (seg < tl.spw && jg < nyg && pos >= 1 && pos <= tl.rem);
+    if (jg >= nyg) jg = nyg - 1;   // idle lanes redo the last group, in bounds, and write nothing
+  }
+  if (ix > a.g.ng[0]) ix = a.g.ng[0];
+  const int j0 = jg * R;
+  const int nrows = (jg_first * R + R <= a.g.ng[1]) ? R : a.g.ng[1] - jg_first * R;
+  const int nrows_l = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
+  const int k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
+  const int kend = (cz < nzc1) ? a.kz1 : a.kz3;
+  const int k1 = (k0 + a.zchunk < kend) ? k0 + a.zchunk : kend;
+
+  const long nc = a.g.ncell, sy = a.g.sy, sz = a.g.sz;
+  const long ncb = nc * 8, syb = sy * 8, szb = sz * 8;   // byte strides (uniform)
+  const char *const Sb = reinterpret_cast<const char *>(a.S);
+  const char *const Hb = reinterpret_cast<const char *>(a.hllflag);
+  const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
+  const bool oa2 = (OAMODE == 0) ? (a.space_ooa == 2) : (OAMODE == 2);
+  const bool hcorr = PLAIN ? false : (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
+  // first-order stages read their stencil from the start-of-step array (time_integrator.cpp:151-250:
+  // Ph == P at the start of a step), so the centre value is the start-of-step state
+  const bool same_pc = (OAMODE == 1) ? true : (a.S == a.Pc);
+  FluxCtx fc = a.fc;
+  if (PLAIN) fc.mp.present = 0;
+  int err = 0;
+  double tdyn = 1.e100, tmp = 1.0e99;  // running minima for the fused time-step reduction
+
+  const int zbase = wave * R * NZ * 64 + lane;
+#define ZS2(r, s) lds[zbase + ((r) * NZ + (s)) * 64]
+
+  const long crow0 = (long)(ix + a.g.nbc[0]) + sy * (j0 + a.g.nbc[1]) + sz * (k0 - 1 + a.g.nbc[2]);
+
+  // z state of the priming plane k0-1 for every row
+#pragma unroll 1
+  for (int r = 0; r < nrows; r++) {
+    if constexpr (ZSL) {
+      const long c = crow0 + sy * ((r < nrows_l) ? r : nrows_l - 1);
+      const unsigned off = (unsigned)c * 8u;
+      double qa[NV], qb[NV], qc[NV], s[NV];
+      load_rot2<NV, MHD>(Sb, ncb, 2, -szb, off, qa);
+      load_rot2<NV, MHD>(Sb, ncb, 2, 0, off, qb);
+      load_rot2<NV, MHD>(Sb, ncb, 2, szb, off, qc);
+      slope3<NV>(qa, qb, qc, dx, oa2, s);
+#pragma unroll
+      for (int v = 0; v < NV; v++) ZS2(r, v) = s[v];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = 0.0;
+  }
+
+#pragma unroll 1
+  for (int k = k0 - 1; k < k1; k++) {
+    const bool prime = (k == k0 - 1);
+    // carried from row to row inside this plane (y sweep frame): flux through the upper y face of the
+    // previous row, y slope of the row being processed
+    double Fy[NV], ysn[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) Fy[v] = ysn[v] = 0.0;
+
+#pragma unroll 1
+    for (int r = 0; r < nrows; r++) {
+      const bool row_ok = (r < nrows_l);
+      const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
+      const unsigned off = (unsigned)c * 8u, offb = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
+      double q0[NV], dU[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) {
+        q0[v] = ldu(Sb + v * ncb, off);
+        dU[v] = 0.0;
+      }
+      if (!PLAIN && !prime && a.dE) {
+        // calc_noRT_microphysics_dU (time_integrator.cpp:438-489): only the energy changes; k_cooling
+        // left PtoU(p_new)[ERG] - PtoU(P)[ERG] of every domain cell (0 elsewhere)
+        dU[uERG] += ldu(reinterpret_cast<const char *>(a.dE), off);
+      }
+      double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;
+
+#pragma unroll 1
+      for (int t = prime ? 3 : 0; t < 4; t++) {
+        if (t == 1 && r > 0) continue;  // lower y face: flux carried from the previous row
+        double eL[NV], eR[NV], f[NV], pstar[NV];
+        long cl, st;
+        int ax;
+        unsigned hfl = 0, hfr = 0;   // HLLD -> HLL switch flags of the two cells of the interface
+        const unsigned zt = opaque_zero();
+        const char *const St = Sb + zt, *const Ht = Hb + zt;
+        if (t == 0) {
+          ax = 0;
+          st = 1;
+          cl = c;
+          if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
+            hfl = ldub(Ht, offb);
+            hfr = ldub(Ht + 1, offb);
+          }
+          if (oa2) {
+            double qm[NV], qp[NV], sx[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              qm[v] = ldu(St + v * ncb - 8, off);
+              qp[v] = ldu(St + v * ncb + 8, off);
+            }
+            slope3<NV>(qm, q0, qp, dx, true, sx);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = q0[v] + sx[v] * dx * 0.5;
+              const double em = q0[v] - sx[v] * dx * 0.5;
+              eR[v] = __shfl_down(em, 1, 64);
+            }
+            if constexpr (MHD) {
+              bnm = qm[qBN];
+              bnp = qp[qBN];
+              if constexpr (EQ == EQGLM) {
+                sim = qm[qSI];
+                sip = qp[qSI];
+              }
+            }
+          }
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = q0[v];
+              eR[v] = __shfl_down(q0[v], 1, 64);
+            }
+            if constexpr (MHD) {
+              // first order: the x neighbours are only needed for B_n and psi, and those are the
+              // neighbouring lanes' own cell values (the end lanes are halo lanes, their result is unused)
+              bnm = __shfl_up(q0[qBN], 1, 64);
+              bnp = eR[qBN];
+              if constexpr (EQ == EQGLM) {
+                sim = __shfl_up(q0[qSI], 1, 64);
+                sip = eR[qSI];
+              }
+            }
+          }
+        }
+        else if (t == 1) {
+          // first row of the group: lower y face (c-sy | c); slopes of rows j-1 and j
+          ax = 1;
+          st = sy;
+          cl = c - sy;
+          if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
+            hfl = ldub(Ht - sy, offb);
+            hfr = ldub(Ht, offb);
+          }
+          double qm1[NV], yq0[NV];
+          load_rot2<NV, MHD>(St, ncb, 1, -syb, off, qm1);
+          to_sweep<NV, MHD>(1, q0, yq0);
+          if (oa2) {
+            double qm2[NV], qp1[NV], sm1[NV];
+            load_rot2<NV, MHD>(St, ncb, 1, -2 * syb, off, qm2);
+            load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
+            slope3<NV>(qm2, qm1, yq0, dx, true, sm1);
+            slope3<NV>(qm1, yq0, qp1, dx, true, ysn);   // this row's slope, used again by the upper face
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = qm1[v] + sm1[v] * dx * 0.5;
+              eR[v] = yq0[v] - ysn[v] * dx * 0.5;
+            }
+          }
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = qm1[v];
+              eR[v] = yq0[v];
+            }
+          }
+        }
+        else if (t == 2) {
+          // upper y face (c | c+sy): this row's slope is ysn (from the lower face or the previous row),
+          // the next row's slope is new and replaces it
+          ax = 1;
+          st = sy;
+          cl = c;
+          if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
+            hfl = ldub(Ht, offb);
+            hfr = ldub(Ht + sy, offb);
+          }
+          double yq0[NV], qp1[NV];
+          load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
+          if constexpr (MHD) {
+            bnm = ldu(St + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
+            if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - syb, off);
+          }
+          to_sweep<NV, MHD>(1, q0, yq0);
+          if (oa2) {
+            double qp2[NV], sp[NV];
+            load_rot2<NV, MHD>(St, ncb, 1, 2 * syb, off, qp2);
+            slope3<NV>(yq0, qp1, qp2, dx, true, sp);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = yq0[v] + ysn[v] * dx * 0.5;
+              eR[v] = qp1[v] - sp[v] * dx * 0.5;
+              ysn[v] = sp[v];
+            }
+          }
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = yq0[v];
+              eR[v] = qp1[v];
+            }
+          }
+          if constexpr (MHD) {
+            bnp = qp1[qBN];
+            if constexpr (EQ == EQGLM) sip = qp1[qSI];
+          }
+        }
+        else {
+          // upper z face (c | c+sz)
+          ax = 2;
+          st = sz;
+          cl = c;
+          if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
+            hfl = ldub(Ht, offb);
+            hfr = ldub(Ht + sz, offb);
+          }
+          double zq0[NV], qp1[NV];
+          load_rot2<NV, MHD>(St, ncb, 2, szb, off, qp1);
+          if constexpr (MHD) {
+            bnm = ldu(St + (long)rotvar<MHD>(2, qBN) * ncb - szb, off);
+            if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - szb, off);
+          }
+          to_sweep<NV, MHD>(2, q0, zq0);
+          if (oa2) {
+            double qp2[NV], sn[NV];
+            load_rot2<NV, MHD>(St, ncb, 2, 2 * szb, off, qp2);
+            slope3<NV>(zq0, qp1, qp2, dx, true, sn);
+#pragma unroll
+            for (int v = 0; v < NV; v++) eR[v] = qp1[v] - sn[v] * dx * 0.5;
+            if constexpr (ZSL) {
+#pragma unroll
+              for (int v = 0; v < NV; v++) {
+                const double sc = ZS2(r, v);
+                eL[v] = zq0[v] + sc * dx * 0.5;
+                ZS2(r, v) = sn[v];
+              }
+            }
+            else {
+              double qm1[NV], sc[NV];
+              load_rot2<NV, MHD>(St, ncb, 2, -szb, off, qm1);
+              slope3<NV>(qm1, zq0, qp1, dx, true, sc);
+#pragma unroll
+              for (int v = 0; v < NV; v++) eL[v] = zq0[v] + sc[v] * dx * 0.5;
+            }
+          }
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = zq0[v];
+              eR[v] = qp1[v];
+            }
+          }
+          if constexpr (MHD) {
+            bnp = qp1[qBN];
+            if constexpr (EQ == EQGLM) sip = qp1[qSI];
+          }
+        }
+
+        double hc_eta = 0.0;
+        if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
+        const bool use_hll = (hfl | hfr) != 0;
+        FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
+
+        if (t == 0) {
+          double Fm[NV];
+#pragma unroll
+          for (int v = 0; v < NV; v++) Fm[v] = __shfl_up(f[v], 1, 64);
+          apply_axis<EQ, NV>(dU, q0, bnm, sim, bnp, sip, Fm, f, dt, dx);
+        }
+        else if (t == 1) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) Fy[v] = f[v];
+        }
+        else if (t == 2) {
+          double d[NV], yq0[NV];
+          to_sweep<NV, MHD>(1, q0, yq0);
+          to_sweep<NV, MHD>(1, dU, d);
+          apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
+          from_sweep<NV, MHD>(1, d, dU);
+#pragma unroll
+          for (int v = 0; v < NV; v++) Fy[v] = f[v];  // lower-face flux of the next row
+        }
+        else {
+          if (!prime) {
+            double d[NV], zq0[NV], Fzl[NV];
+            to_sweep<NV, MHD>(2, q0, zq0);
+            to_sweep<NV, MHD>(2, dU, d);
+#pragma unroll
+            for (int v = 0; v < NV; v++) Fzl[v] = ZS2(r, NZ - NV + v);
+            apply_axis<EQ, NV>(d, zq0, bnm, sim, bnp, sip, Fzl, f, dt, dx);
+            from_sweep<NV, MHD>(2, d, dU);
+          }
+#pragma unroll
+          for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = f[v];
+        }
+      }
+
+      if (!prime && writer && row_ok) {
+        const unsigned fl = ldub(reinterpret_cast<const char *>(a.flags) + opaque_zero(), offb);
+        double P0[NV], Pf[NV];
+        if (same_pc) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) P0[v] = q0[v];
+        }
+        else {
+#pragma unroll
+          for (int v = 0; v < NV; v++) P0[v] = ldu(reinterpret_cast<const char *>(a.Pc) + v * ncb, off);
+        }
+        if (!(fl & 4) || !(fl & 16)) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) Pf[v] = P0[v];
+        }
+        else cell_update<EQ, NTR>(a, P0, dU, err, Pf, PLAIN);
+#pragma unroll
+        for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb, off, Pf[v]);
+        if (a.dtres) {
+          // calc_dynamics_dt / calc_microphysics_dt (calc_timestep.cpp:271-507) of the state just
+          // written: after a full step it is the state the next step's dt is computed from
+          if ((fl & 8) && !(fl & 2)) {
+            const double t = cell_dt<EQ>(Pf, a.g.ndim, g, dx, a.cfl);
+            if (!(t > 0.0)) err |= ERR_BAD_DT;
+            tdyn = (t < tdyn) ? t : tdyn;
+          }
+          if (a.dt_mp && !(fl & 2) && (fl & 16)) {
+            const double t = Cooling::timescale(a.cool, Pf[qRO], Pf[qPG], g);
+            tmp = (t < tmp) ? t : tmp;
+          }
+        }
+      }
+    }
+  }
+#undef ZS2
+  if (a.dtres) {
+    tdyn = wave_min64(tdyn);
+    tmp = wave_min64(tmp);
+    if (lane == 0) {
+      atomicMin(&a.dtres[0], (unsigned long long)__double_as_longlong(tdyn));
+      atomicMin(&a.dtres[1], (unsigned long long)__double_as_longlong(tmp));
+    }
+  }
+  if (err) atomicOr(a.errword, err);
+}
+
+// rows per wavefront the LDS budget allows
+template <int NV, bool ZSL>
+__host__ inline int rows2_rmax()
+{
+  constexpr int NZ = ZSL ? 2 * NV : NV;
+  int r = (int)(PION_ROWS2_LDS_BYTES / (sizeof(double) * 4 * NZ * 64));
+  return r > 8 ? 8 : r;
+}
+
+template <int EQ, int NTR, int SOLVER, bool ZSL>
+static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
+{
+  constexpr int NV = Eqn<EQ, NTR>::NV;
+  constexpr int NZ = ZSL ? 2 * NV : NV;
+  StageArgs a = a0;
+  const int rmax = rows2_rmax<NV, ZSL>();
+  if (a.rows > rmax) a.rows = rmax;
+  if (a.rows < 1) a.rows = 1;
+  const int R = a.rows;
+  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
+  const long ntiles = (long)rows_tiling(a).per_chunk * nzc;
+  const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
+  const size_t shmem = sizeof(double) * 4 * R * NZ * 64;
+  // compile-time spatial order and "no H-correction / microphysics" for the production instances
+  // (MHD HLLD, Euler Roe-CV, Euler FVS), run-time for the others
+  constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)
+                              || ((SOLVER == FLUX_RSroe || SOLVER == FLUX_FVS) && EQ == EQEUL);
+  if constexpr (specialise) {
+    const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
+                        && a.fc.artvisc != AV_HCORR_FKJ98);
+    if (plain) {
+      if (a.space_ooa == 2)
+        hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 2, true, ZSL>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+      else
+        hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 1, true, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+    }
+    else if (a.space_ooa == 2)
+      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 2, false, ZSL>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+    else
+      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 1, false, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+  }
+  else
+    hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 0, false, ZSL>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+  return (int)hipGetLastError();
+}
+
+template <int EQ, int NTR, int SOLVER>
+static int stage_rows2_go(const StageArgs &a, hipStream_t s)
+{
+  // a.zslope_lds: carry the z slope in LDS (fewer rows per wavefront) instead of rebuilding it
+  if (a.zslope_lds && a.space_ooa == 2) return stage_rows2_go_z<EQ, NTR, SOLVER, true>(a, s);
+  return stage_rows2_go_z<EQ, NTR, SOLVER, false>(a, s);
+}
+
+#endif
