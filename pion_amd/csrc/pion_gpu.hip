@@ -279,7 +279,7 @@ struct Handle {
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
   int use_march = 3, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
-  int zslope_lds = 0;     // k_stage_rows2: carry the z slope in LDS (PION_ZSLOPE_LDS=1) instead of rebuilding it
+  int zslope_lds = 1;     // k_stage_rows2: carry the z slope in LDS (default; PION_ZSLOPE_LDS=0: rebuild it from plane k-1, R = 4)
   double *ddE = nullptr;  // cooling source per cell (k_cooling_dE -> k_stage_rows2)
   bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
   bool fuse_bc = true;    // PION_FUSE_BC=0: periodic faces one launch per face (A/B)

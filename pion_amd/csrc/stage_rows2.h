@@ -74,6 +74,30 @@ PDEV void load_rot2(const char *Sb, const long ncb, const int ax, const long sh,
   for (int s = 0; s < NV; s++) q[s] = ldu(Sb + (long)rotvar<MHD>(ax, s) * ncb + sh, off);
 }
 
+// SetSlope x dx for one cell from its two neighbours (VectorOps.cpp:578-617, AvgFalle :37-59): the edge
+// states are q -+ hs / 2 (SetEdgeState :535-571).  Strict build: the reference's slope s = minmod(a/dx, b/dx)
+// (division form) times dx, so that q + hs * 0.5 is the reference's q + s * dx * 0.5 bit for bit.  Fast
+// build: minmod of the raw differences -- min(|a|, |b|) with the sign of a where a b > 1e-200 dx^2 -- no
+// division and no scaling by dx and back (<= 1 ulp from the reference form).
+template <int NV>
+PDEV void hslope3(const double *qm, const double *q0, const double *qp, const double dx, const double thr, double *hs)
+{
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+#ifdef PION_FAST_MATH
+    const double a = q0[v] - qm[v], b = qp[v] - q0[v];
+    const double m = __builtin_copysign(__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)), a);
+    hs[v] = (a * b <= thr) ? 0.0 : m;
+#else
+    hs[v] = avg_falle((q0[v] - qm[v]) / dx, (qp[v] - q0[v]) / dx) * dx;
+#endif
+  }
+}
+
+#ifndef PION_ROWS2_PF
+#define PION_ROWS2_PF 1
+#endif
+
 template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN, bool ZSL>
 __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
 {
@@ -82,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
   constexpr int NV = E::NV;
   constexpr bool MHD = E::MHD;
   constexpr int NZ = ZSL ? 2 * NV : NV;   // LDS slots per row: [z slope,] lower z flux
+  constexpr bool PF = PION_ROWS2_PF && (OAMODE == 1);
   extern __shared__ double lds[];
 
   const int R = a.rows;
@@ -126,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
   const char *const Hb = reinterpret_cast<const char *>(a.hllflag);
   const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
   const bool oa2 = (OAMODE == 0) ? (a.space_ooa == 2) : (OAMODE == 2);
+  const double thr = PION_VERY_TINY_VALUE * dx * dx;   // AvgFalle's zero test on raw differences (fast build)
   const bool hcorr = PLAIN ? false : (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
   // first-order stages read their stencil from the start-of-step array (time_integrator.cpp:151-250:
   // Ph == P at the start of a step), so the centre value is the start-of-step state
@@ -150,13 +176,26 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
       load_rot2<NV, MHD>(Sb, ncb, 2, -szb, off, qa);
       load_rot2<NV, MHD>(Sb, ncb, 2, 0, off, qb);
       load_rot2<NV, MHD>(Sb, ncb, 2, szb, off, qc);
-      slope3<NV>(qa, qb, qc, dx, oa2, s);
+      if (oa2) hslope3<NV>(qa, qb, qc, dx, thr, s);
+      else {
+#pragma unroll
+        for (int v = 0; v < NV; v++) s[v] = 0.0;
+      }
 #pragma unroll
       for (int v = 0; v < NV; v++) ZS2(r, v) = s[v];
     }
 #pragma unroll
     for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = 0.0;
   }
+
+  // PF (first-order instances): what the NEXT task needs from memory -- one row of the state, B_n / psi of
+  // the lower neighbour, two switch flags -- is requested before the current Riemann solve and consumed
+  // after it, so that the task starts without a wait (the second-order instances need two or three rows
+  // per task and have no registers left for them)
+  double pf[NV], pfb = 0.0, pfs = 0.0;
+  unsigned pfh = 0;
+#pragma unroll
+  for (int v = 0; v < NV; v++) pf[v] = 0.0;
 
 #pragma unroll 1
   for (int k = k0 - 1; k < k1; k++) {
@@ -172,12 +211,21 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
       const bool row_ok = (r < nrows_l);
       const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
       const unsigned off = (unsigned)c * 8u, offb = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
+      // the row visited after this one (next row of the plane, or the first row of the next plane)
+      const long cn = (r + 1 < nrows) ? crow0 + sy * ((r + 1 < nrows_l) ? r + 1 : nrows_l - 1) + sz * (k - (k0 - 1))
+                                      : crow0 + sz * (k + 1 - (k0 - 1));
+      const unsigned offn = (unsigned)cn * 8u, offnb = (unsigned)cn;
       double q0[NV], dU[NV];
+      if (PF && !prime) {
 #pragma unroll
-      for (int v = 0; v < NV; v++) {
-        q0[v] = ldu(Sb + v * ncb, off);
-        dU[v] = 0.0;
+        for (int v = 0; v < NV; v++) q0[v] = pf[v];   // requested before the previous row's last solve
       }
+      else {
+#pragma unroll
+        for (int v = 0; v < NV; v++) q0[v] = ldu(Sb + v * ncb, off);
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++) dU[v] = 0.0;
       if (!PLAIN && !prime && a.dE) {
         // calc_noRT_microphysics_dU (time_integrator.cpp:438-489): only the energy changes; k_cooling
         // left PtoU(p_new)[ERG] - PtoU(P)[ERG] of every domain cell (0 elsewhere)
@@ -199,8 +247,11 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
           st = 1;
           cl = c;
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            hfl = ldub(Ht, offb);
-            hfr = ldub(Ht + 1, offb);
+            if (PF) hfl = pfh;   // (both flags, packed)
+            else {
+              hfl = ldub(Ht, offb);
+              hfr = ldub(Ht + 1, offb);
+            }
           }
           if (oa2) {
             double qm[NV], qp[NV], sx[NV];
@@ -209,11 +260,11 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
               qm[v] = ldu(St + v * ncb - 8, off);
               qp[v] = ldu(St + v * ncb + 8, off);
             }
-            slope3<NV>(qm, q0, qp, dx, true, sx);
+            hslope3<NV>(qm, q0, qp, dx, thr, sx);
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-              eL[v] = q0[v] + sx[v] * dx * 0.5;
-              const double em = q0[v] - sx[v] * dx * 0.5;
+              eL[v] = q0[v] + sx[v] * 0.5;
+              const double em = q0[v] - sx[v] * 0.5;
               eR[v] = __shfl_down(em, 1, 64);
             }
             if constexpr (MHD) {
@@ -249,22 +300,29 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
           st = sy;
           cl = c - sy;
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            hfl = ldub(Ht - sy, offb);
-            hfr = ldub(Ht, offb);
+            if (PF) hfl = pfh;
+            else {
+              hfl = ldub(Ht - sy, offb);
+              hfr = ldub(Ht, offb);
+            }
           }
           double qm1[NV], yq0[NV];
-          load_rot2<NV, MHD>(St, ncb, 1, -syb, off, qm1);
+          if (PF) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qm1[v] = pf[v];
+          }
+          else load_rot2<NV, MHD>(St, ncb, 1, -syb, off, qm1);
           to_sweep<NV, MHD>(1, q0, yq0);
           if (oa2) {
             double qm2[NV], qp1[NV], sm1[NV];
             load_rot2<NV, MHD>(St, ncb, 1, -2 * syb, off, qm2);
             load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
-            slope3<NV>(qm2, qm1, yq0, dx, true, sm1);
-            slope3<NV>(qm1, yq0, qp1, dx, true, ysn);   // this row's slope, used again by the upper face
+            hslope3<NV>(qm2, qm1, yq0, dx, thr, sm1);
+            hslope3<NV>(qm1, yq0, qp1, dx, thr, ysn);   // this row's slope, used again by the upper face
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-              eL[v] = qm1[v] + sm1[v] * dx * 0.5;
-              eR[v] = yq0[v] - ysn[v] * dx * 0.5;
+              eL[v] = qm1[v] + sm1[v] * 0.5;
+              eR[v] = yq0[v] - ysn[v] * 0.5;
             }
           }
           else {
@@ -282,24 +340,35 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
           st = sy;
           cl = c;
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            hfl = ldub(Ht, offb);
-            hfr = ldub(Ht + sy, offb);
+            if (PF) hfl = pfh;
+            else {
+              hfl = ldub(Ht, offb);
+              hfr = ldub(Ht + sy, offb);
+            }
           }
           double yq0[NV], qp1[NV];
-          load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
-          if constexpr (MHD) {
-            bnm = ldu(St + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
-            if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - syb, off);
+          if (PF) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp1[v] = pf[v];
+            bnm = pfb;
+            sim = pfs;
+          }
+          else {
+            load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
+            if constexpr (MHD) {
+              bnm = ldu(St + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
+              if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - syb, off);
+            }
           }
           to_sweep<NV, MHD>(1, q0, yq0);
           if (oa2) {
             double qp2[NV], sp[NV];
             load_rot2<NV, MHD>(St, ncb, 1, 2 * syb, off, qp2);
-            slope3<NV>(yq0, qp1, qp2, dx, true, sp);
+            hslope3<NV>(yq0, qp1, qp2, dx, thr, sp);
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-              eL[v] = yq0[v] + ysn[v] * dx * 0.5;
-              eR[v] = qp1[v] - sp[v] * dx * 0.5;
+              eL[v] = yq0[v] + ysn[v] * 0.5;
+              eR[v] = qp1[v] - sp[v] * 0.5;
               ysn[v] = sp[v];
             }
           }
@@ -321,36 +390,47 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
           st = sz;
           cl = c;
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            hfl = ldub(Ht, offb);
-            hfr = ldub(Ht + sz, offb);
+            if (PF && !(prime && r == 0)) hfl = pfh;
+            else {
+              hfl = ldub(Ht, offb);
+              hfr = ldub(Ht + sz, offb);
+            }
           }
           double zq0[NV], qp1[NV];
-          load_rot2<NV, MHD>(St, ncb, 2, szb, off, qp1);
-          if constexpr (MHD) {
-            bnm = ldu(St + (long)rotvar<MHD>(2, qBN) * ncb - szb, off);
-            if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - szb, off);
+          if (PF && !(prime && r == 0)) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) qp1[v] = pf[v];
+            bnm = pfb;
+            sim = pfs;
+          }
+          else {
+            load_rot2<NV, MHD>(St, ncb, 2, szb, off, qp1);
+            if constexpr (MHD) {
+              bnm = ldu(St + (long)rotvar<MHD>(2, qBN) * ncb - szb, off);
+              if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - szb, off);
+            }
           }
           to_sweep<NV, MHD>(2, q0, zq0);
           if (oa2) {
             double qp2[NV], sn[NV];
             load_rot2<NV, MHD>(St, ncb, 2, 2 * szb, off, qp2);
-            slope3<NV>(zq0, qp1, qp2, dx, true, sn);
+            hslope3<NV>(zq0, qp1, qp2, dx, thr, sn);
 #pragma unroll
-            for (int v = 0; v < NV; v++) eR[v] = qp1[v] - sn[v] * dx * 0.5;
+            for (int v = 0; v < NV; v++) eR[v] = qp1[v] - sn[v] * 0.5;
             if constexpr (ZSL) {
 #pragma unroll
               for (int v = 0; v < NV; v++) {
                 const double sc = ZS2(r, v);
-                eL[v] = zq0[v] + sc * dx * 0.5;
+                eL[v] = zq0[v] + sc * 0.5;
                 ZS2(r, v) = sn[v];
               }
             }
             else {
               double qm1[NV], sc[NV];
               load_rot2<NV, MHD>(St, ncb, 2, -szb, off, qm1);
-              slope3<NV>(qm1, zq0, qp1, dx, true, sc);
+              hslope3<NV>(qm1, zq0, qp1, dx, thr, sc);
 #pragma unroll
-              for (int v = 0; v < NV; v++) eL[v] = zq0[v] + sc[v] * dx * 0.5;
+              for (int v = 0; v < NV; v++) eL[v] = zq0[v] + sc[v] * 0.5;
             }
           }
           else {
@@ -369,6 +449,49 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         double hc_eta = 0.0;
         if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
         const bool use_hll = (hfl | hfr) != 0;
+        if (PF) {
+          // requests for the task that follows this solve
+          const unsigned zp = opaque_zero();
+          const char *const Sp = Sb + zp, *const Hp = Hb + zp;
+          if (t == 3) {
+            // next: the x task of the next row; in the priming plane, where every row runs the z task
+            // only, the z task of the next row (after its last row: the x task of the first row of the
+            // next plane)
+            if (prime && r + 1 < nrows) {
+              load_rot2<NV, MHD>(Sp, ncb, 2, szb, offn, pf);
+              if constexpr (MHD) {
+                pfb = ldu(Sp + (long)rotvar<MHD>(2, qBN) * ncb - szb, offn);
+                if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb - szb, offn);
+              }
+              if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offnb) | ldub(Hp + sz, offnb);
+            }
+            else {
+#pragma unroll
+              for (int v = 0; v < NV; v++) pf[v] = ldu(Sp + v * ncb, offn);
+              if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offnb) | ldub(Hp + 1, offnb);
+            }
+          }
+          else if (t == 0 && r == 0) {
+            load_rot2<NV, MHD>(Sp, ncb, 1, -syb, off, pf);
+            if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp - sy, offb) | ldub(Hp, offb);
+          }
+          else if (t == 0 || t == 1) {
+            load_rot2<NV, MHD>(Sp, ncb, 1, syb, off, pf);
+            if constexpr (MHD) {
+              pfb = ldu(Sp + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
+              if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb - syb, off);
+            }
+            if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offb) | ldub(Hp + sy, offb);
+          }
+          else {   // t == 2: the z task of this row
+            load_rot2<NV, MHD>(Sp, ncb, 2, szb, off, pf);
+            if constexpr (MHD) {
+              pfb = ldu(Sp + (long)rotvar<MHD>(2, qBN) * ncb - szb, off);
+              if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb - szb, off);
+            }
+            if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offb) | ldub(Hp + sz, offb);
+          }
+        }
         FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 
         if (t == 0) {
