@@ -136,6 +136,12 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
                          "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
+    ap.add_argument("--transport", default="host", choices=["host", "torch"],
+                    help="who drives the time loop and the N>1 transport: host (default) = the C++ host layer "
+                         "(pion_host::sim_control_gpu + slab_comm_rccl: RCCL send/recv groups and the dt all-reduce "
+                         "issued from C++; torch.distributed/gloo only broadcasts the ncclUniqueId and hosts the "
+                         "timing barrier); torch = the Python driver with torch.distributed P2P (round-1 path; "
+                         "required for --backend gloo)")
     ap.add_argument("--nz", type=int, default=0,
                     help="m1 only: cells along z if not --n (with --loopback and nz = n/N this is exactly the slab, the "
                          "launches and the transfers of one rank of an N-rank run)")
@@ -170,7 +176,12 @@ def main():
 
     comm = None
     torch = None
-    if world > 1:
+    use_host = (args.transport == "host" and args.backend == "nccl")
+    if world > 1 and use_host:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")   # bootstrap (ncclUniqueId) and timing barrier only
+    elif world > 1:
         import torch
         import torch.distributed as dist
         if args.backend == "nccl":
@@ -182,7 +193,7 @@ def main():
             dist.init_process_group("gloo")
 
     loopback = args.loopback and world == 1 and args.workload == "m1"
-    if loopback:
+    if loopback and not use_host:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(0)
@@ -193,6 +204,23 @@ def main():
     wl_name = None
     dt_lim = None
     periodic_z = True
+    hs = None
+
+    def make_sim(cfg, periodic_z):
+        """the handle the benchmark drives: owned by the C++ host layer (transport host) or by Python"""
+        if not use_host:
+            return None, lib.GpuSim(cfg, local_rank)
+        from pion_amd import host_rccl
+        uid = None
+        if world > 1:
+            box = [host_rccl.new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        elif loopback:
+            uid = host_rccl.new_unique_id()
+        h = host_rccl.HostSim(cfg, local_rank, rank=rank, world=world, periodic_z=periodic_z, unique_id=uid)
+        return h, lib.GpuSim(cfg, borrowed_handle=h.gpu_handle())
+
     if args.workload == "m1":
         cfg_g, _ = problems.mhd_blastwave(4, 3, eq, solver, strict_fp=args.strict)  # template
         cfg_g.ng[0] = cfg_g.ng[1] = cfg_g.ng[2] = n
@@ -203,7 +231,7 @@ def main():
         if loopback:
             cfg.bc_type[4] = cfg.bc_type[5] = abi.BC_SLAB
         P = problems.fill_mhd_blastwave(cfg)
-        sim = lib.GpuSim(cfg, local_rank)
+        hs, sim = make_sim(cfg, True)
     elif args.workload == "m2":
         # BASELINE configs[3]: 3-D HD blast 512^3, z-slabs over the GPUs (physical z faces on the end ranks)
         cfg_g, _ = problems.hd_blast_octant(4, 3, solver=abi.FLUX_RSroe, strict_fp=args.strict)   # template
@@ -214,7 +242,7 @@ def main():
         P = problems.fill_hd_blast_octant(cfg, n / 32.0)
         wl_name = "M2: 3-D Euler octant Sedov blast %d^3, Roe-CV + FKJ98 0.1, reflecting/outflow, OA2/OA2" % n
         periodic_z = False
-        sim = lib.GpuSim(cfg, local_rank)
+        hs, sim = make_sim(cfg, False)
         eq = cfg.eqntype
     else:
         # BASELINE configs[4]: Wind3D with the cooling source term, z-slabs over the GPUs
@@ -228,41 +256,50 @@ def main():
         wl_name = ("M3: Wind3D single level %d^3, Euler + tracer, FVS + FKJ98 0.15, cooling 8, stellar wind, "
                    "reflecting/one-way, OA2/OA2" % n)
         periodic_z = False
-        sim = lib.GpuSim(cfg, local_rank)
+        hs, sim = make_sim(cfg, False)
         sim.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
         if widx.size:
             sim.set_wind_cells(widx, wst)   # (ranks away from the source hold no wind cell)
         eq = cfg.eqntype
-    if world > 1 or loopback:
-        comm = slab.SlabComm(rank, world, periodic_z, sim.halo_count(), torch.device("cuda", local_rank),
-                             loopback=loopback)
-        comm.use_streams(sim)   # exchange under the interior part of each stage, no host waits
-    sc = driver.SimControl(sim, cfg, comm=comm)
-    sc.first_step_dt_limit = dt_lim
-    sc.init(P)
+    if hs is not None:
+        hs.init(P, first_step_dt_limit=dt_lim)
+        step = hs.step
+        finish_halo = hs.finish_halo
+    else:
+        if world > 1 or loopback:
+            comm = slab.SlabComm(rank, world, periodic_z, sim.halo_count(), torch.device("cuda", local_rank),
+                                 loopback=loopback)
+            comm.use_streams(sim)   # exchange under the interior part of each stage, no host waits
+        sc = driver.SimControl(sim, cfg, comm=comm)
+        sc.first_step_dt_limit = dt_lim
+        sc.init(P)
+        finish_halo = sc.finish_halo
+
+        def step():
+            sc.calculate_timestep()
+            sc.advance_time()
     del P
 
     def barrier():
-        sc.finish_halo()
+        finish_halo()
         sim.synchronize()
-        if world > 1 or loopback:
+        if hs is None and (world > 1 or loopback):
             torch.cuda.synchronize()
+        if world > 1:
             dist.barrier()
 
     for _ in range(args.warmup):
-        sc.calculate_timestep()
-        sc.advance_time()
+        step()
     sim.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sc.calculate_timestep()
-        sc.advance_time()
+        step()
     barrier()
     el = time.perf_counter() - t0
     tm = sim.get_timing()
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if (args.backend == "nccl" and hs is None) else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -307,14 +344,16 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl_name or "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
                                    % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
-                       "grid": [int(v) for v in cfg_g.ng[:3]], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": "RCCL send/recv to self (loopback)" if loopback else "none" if world == 1 else
-                       ("RCCL P2P" if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"),
+                       "grid": [int(v) for v in cfg_g.ng[:3]], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": ("RCCL send/recv to self (loopback)" if loopback else "none" if world == 1 else
+                                     ("RCCL P2P" if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"))
+                       + ("; time loop and transport issued from C++ (libpion_host)" if hs is not None else "; Python driver"),
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
-                         "kernel": {"m1": "k_stage_rows<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows<MHD,0,HLLD>",
-                                    "m2": "k_stage_rows<EUL,0,Roe-CV>", "m3": "k_stage_rows<EUL,1,FVS>"}[args.workload],
+                         "kernel": {"m1": "k_stage_rows2<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows2<MHD,0,HLLD>",
+                                    "m2": "k_stage_rows2<EUL,0,Roe-CV>", "m3": "k_stage_rows2<EUL,1,FVS>"}[args.workload]
+                                   + " (first-order + second-order instance, mean per launch)",
                          "kernel_ms": stage_ms, "launches_per_stage": tm["stage_n"] / (2.0 * args.steps), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes, "issue": valu},
         }
@@ -325,11 +364,16 @@ def main():
             # operation order, bit-identical to the oracle): its throughput beside the headline
             sim.close()
             sim = None
+            if hs is not None:
+                hs.close()
+                hs = None
             out["parity_build"] = parity_build_run(args, cfg, local_rank, dt_lim)
         print(json.dumps(out))
     if sim is not None:
         sim.close()
-    if world > 1 or loopback:
+    if hs is not None:
+        hs.close()
+    if world > 1 or (loopback and not use_host):
         dist.destroy_process_group()
 
 

@@ -154,6 +154,8 @@ int pion_gpu_set_stream(void *handle, void *stream);
  * The library orders pack after the compute stream's work so far and PION_STAGE_ZBOUNDARY after the
  * last unpack; the caller's transfer (RCCL/MPI) must be enqueued on, or ordered with, this stream. */
 int pion_gpu_set_comm_stream(void *handle, void *stream);
+/* the handle's streams (hipStream_t): which = 0 compute, 1 comm */
+void *pion_gpu_get_stream(void *handle, int which);
 int pion_gpu_synchronize(void *handle);
 
 /* internal fixed-state cells: stellar wind (grid/stellar_wind_BC.cpp:642-677,
@@ -192,6 +194,16 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
  * solver_eqn_mhd_adi.cpp:516-582) and MP->timescales
  * (mp_only_cooling.cpp:333-368).  No limiting is applied here. */
 int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp);
+/* The same reduction in two halves, for slab-decomposed runs (sim_control_MPI.cpp:503-504 does
+ * COMM->global_operation_double("MIN", .) on the host value; here the minimum stays on the device
+ * until it has been reduced over the ranks):
+ *   pion_gpu_calc_dt_device  enqueues the reduction (nothing, when the last full stage left the minima
+ *                            behind) and returns the device address of {min t_dyn, min t_mp} (2 doubles);
+ *                            no host synchronisation.  The caller may all-reduce(min) that buffer in place
+ *                            on the handle's compute stream (ncclAllReduce(ncclMin)).
+ *   pion_gpu_read_dt         the single 16-byte read-back + the device error word. */
+int pion_gpu_calc_dt_device(void *handle, void **dptr);
+int pion_gpu_read_dt(void *handle, double *t_dyn, double *t_mp);
 
 /* FV_solver_mhd_mixedGLM_adi::Set_GLM_Speeds (solver_eqn_mhd_adi.cpp:906-922):
  * c_h = CFL*dx/dt, c_r = cr. */

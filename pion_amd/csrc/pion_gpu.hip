@@ -910,7 +910,7 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
   return 0;
 }
 
-int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
+int pion_gpu_calc_dt_device(void *handle, void **dptr)
 {
   Handle *h = use(handle);
   DtArgs a;
@@ -940,13 +940,33 @@ int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
       h->err = "dt kernel launch failed";
       return PION_GPU_EDEVICE;
     }
+    h->dt_cached = true;
   }
+  if (dptr) *dptr = h->ddt;
+  return 0;
+}
+
+int pion_gpu_read_dt(void *handle, double *t_dyn, double *t_mp)
+{
+  Handle *h = use(handle);
   double out[2];
   HCHECK(h, hipMemcpyAsync(out, h->ddt, sizeof out, hipMemcpyDeviceToHost, h->stream));
   HCHECK(h, hipStreamSynchronize(h->stream));
   *t_dyn = out[0];
   *t_mp = out[1];
   return check_errword(h);
+}
+
+int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
+{
+  if (int rc = pion_gpu_calc_dt_device(handle, nullptr)) return rc;
+  return pion_gpu_read_dt(handle, t_dyn, t_mp);
+}
+
+void *pion_gpu_get_stream(void *handle, int which)
+{
+  Handle *h = use(handle);
+  return (void *)(which == 0 ? h->stream : (h->comm_stream ? h->comm_stream : h->stream));
 }
 
 int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr)

@@ -1,6 +1,8 @@
 // sim_control_gpu.cpp -- see sim_control_gpu.h
 #include "sim_control_gpu.h"
 
+#include "slab_comm_rccl.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <stdexcept>
@@ -29,19 +31,47 @@ std::string sim_control_gpu::last_error() const
   return buf;
 }
 
+int sim_control_gpu::set_comm(slab_comm_rccl *c)
+{
+  comm_ = c;
+  return c ? c->attach(h_) : 0;
+}
+
+// TimeUpdateInternalBCs + TimeUpdateExternalBCs, then (slab runs) the start of BC_update_BCMPI for the
+// array that was just written; stage() completes it between its two parts
+int sim_control_gpu::update_boundaries(int cstep, int maxstep, int assign)
+{
+  int err = pion_gpu_update_bcs(h_, T.simtime, cstep, maxstep, assign);
+  if (comm_ && !err) err += comm_->start(cstep == maxstep ? 0 : 1);
+  return err;
+}
+
+int sim_control_gpu::stage(double dt, int space_ooa, int is_full)
+{
+  if (!comm_) return pion_gpu_stage(h_, dt, space_ooa, is_full);
+  int err = pion_gpu_stage_part(h_, dt, space_ooa, is_full, PION_STAGE_INTERIOR);
+  err += comm_->finish();
+  err += pion_gpu_stage_part(h_, dt, space_ooa, is_full, PION_STAGE_ZBOUNDARY);
+  return err;
+}
+
+int sim_control_gpu::finish_halo() { return comm_ ? comm_->finish() : 0; }
+
 int sim_control_gpu::Init(const double *P_soa, double simtime)
 {
   T.simtime = simtime;
   int err = pion_gpu_upload(h_, P_soa);
   // assign_boundary_data + TimeUpdateInternalBCs/ExternalBCs (sim_init.cpp:246-267)
-  err += pion_gpu_update_bcs(h_, T.simtime, cfg.tm_ooa, cfg.tm_ooa, 1);
+  err += update_boundaries(cfg.tm_ooa, cfg.tm_ooa, 1);
   return err;
 }
 
 int sim_control_gpu::calculate_timestep()
 {
   double t_dyn = 0.0, t_mp = 0.0;
-  int err = pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
+  // slab runs: the minima stay on the device until they are reduced over the ranks
+  // (COMM->global_operation_double("MIN", .), sim_control_MPI.cpp:503-504)
+  int err = comm_ ? comm_->allreduce_min(&t_dyn, &t_mp) : pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
   if (err) return err;
   if (T.timestep == 0 && T.first_step_dt_limit > 0.0) t_dyn = std::min(t_dyn, T.first_step_dt_limit);
   T.dt = std::min(t_dyn, t_mp);
@@ -58,11 +88,11 @@ int sim_control_gpu::calculate_timestep()
 int sim_control_gpu::first_order_update(double dt, int ooa)
 {
   // Setdt, calc_microphysics_dU, calc_dynamics_dU(OA1), grid_update_state_vector(dt, OA1, ooa)
-  return pion_gpu_stage(h_, dt, 1, ooa == 1 ? 1 : 0);
+  return stage(dt, 1, ooa == 1 ? 1 : 0);
 }
 int sim_control_gpu::second_order_update(double dt, int)
 {
-  return pion_gpu_stage(h_, dt, 2, 1);
+  return stage(dt, 2, 1);
 }
 
 double sim_control_gpu::advance_time()
@@ -70,13 +100,13 @@ double sim_control_gpu::advance_time()
   int err = 0;
   if (cfg.tm_ooa == 1 && cfg.sp_ooa == 1) {
     err += first_order_update(T.dt, cfg.tm_ooa);
-    err += pion_gpu_update_bcs(h_, T.simtime, 1, 1, 0);
+    err += update_boundaries(1, 1, 0);
   }
   else if (cfg.tm_ooa == 2 && cfg.sp_ooa == 2) {
     err += first_order_update(0.5 * T.dt, 2);
-    err += pion_gpu_update_bcs(h_, T.simtime, 1, 2, 0);
+    err += update_boundaries(1, 2, 0);
     err += second_order_update(T.dt, 2);
-    err += pion_gpu_update_bcs(h_, T.simtime, 2, 2, 0);
+    err += update_boundaries(2, 2, 0);
   }
   else throw std::runtime_error("Bad OOA requests; choose (1,1) or (2,2)");
   if (err) throw std::runtime_error("advance_time: " + last_error());
@@ -95,6 +125,7 @@ int sim_control_gpu::Time_Int(int nsteps)
     advance_time();
     n++;
   }
+  if (finish_halo()) throw std::runtime_error("finish_halo: " + last_error());
   return n;
 }
 
@@ -152,6 +183,32 @@ int pion_host_sim_last_error(void *s, char *buf, int len)
 }
 int pion_host_sim_download(void *s, int which, double *P)
 {
-  return static_cast<pion_host::sim_control_gpu *>(s)->download(which, P);
+  auto *c = static_cast<pion_host::sim_control_gpu *>(s);
+  if (int rc = c->finish_halo()) return rc;
+  return c->download(which, P);
+}
+int pion_host_sim_finish_halo(void *s) { return static_cast<pion_host::sim_control_gpu *>(s)->finish_halo(); }
+// hand the sim a slab communicator (pion_host_comm_create); call before pion_host_sim_init
+int pion_host_sim_set_comm(void *s, void *comm)
+{
+  return static_cast<pion_host::sim_control_gpu *>(s)->set_comm(static_cast<pion_host::slab_comm_rccl *>(comm));
+}
+// one step at a time (bench.py times K of them between barriers)
+int pion_host_sim_step(void *s, double *dt)
+{
+  auto *c = static_cast<pion_host::sim_control_gpu *>(s);
+  try {
+    int err = c->calculate_timestep();
+    if (err) {
+      g_last_exception = "calculate_timestep: " + c->last_error();
+      return err;
+    }
+    *dt = c->advance_time();
+    return 0;
+  }
+  catch (const std::exception &e) {
+    g_last_exception = e.what();
+    return -1;
+  }
 }
 }

@@ -19,6 +19,8 @@
 
 namespace pion_host {
 
+class slab_comm_rccl;   // slab_comm_rccl.h
+
 // the slice of SimParams (sim_params.h:200-285) the time loop itself reads/writes
 struct SimTime {
   double simtime = 0.0, finishtime = 1e300, dt = 0.0, last_dt = 1e100, min_timestep = 0.0;
@@ -43,6 +45,14 @@ class sim_control_gpu {
   // sim_control::Time_Int without I/O; nsteps<0: until finishtime
   int Time_Int(int nsteps);
 
+  // z-slab of a larger domain: exchange the z ghost planes after every boundary update (under the
+  // interior part of the next stage) and min-reduce the time step over the ranks
+  // (sim_control_pllel, sim_control_MPI.cpp:482-583; MCMD_boundaries.cpp:122-237)
+  int set_comm(slab_comm_rccl *c);
+  int update_boundaries(int cstep, int maxstep, int assign);
+  int stage(double dt, int space_ooa, int is_full);
+  int finish_halo();
+
   int download(int which, double *P_soa) { return pion_gpu_download(h_, which, P_soa); }
   void *handle() { return h_; }
   std::string last_error() const;
@@ -52,6 +62,7 @@ class sim_control_gpu {
 
  private:
   void *h_;
+  slab_comm_rccl *comm_ = nullptr;
 };
 
 }  // namespace pion_host

@@ -1,0 +1,135 @@
+"""ctypes view of the C++ host layer above the C-ABI (pion_amd/host/libpion_host.so):
+pion_host::sim_control_gpu (the Time_Int / calculate_timestep / advance_time mirror) and
+pion_host::slab_comm_rccl (z-slab halo exchange + time-step reduction over RCCL, driven from C++:
+ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the communication stream, ncclAllReduce(ncclMin) on
+the device-resident minima).  Python only hands over configuration, the initial state and -- for N > 1 -- the
+128-byte ncclUniqueId it broadcast; every launch, transfer and reduction of the time loop is issued from C++.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+_host = None
+
+UNIQUE_ID_BYTES = 128
+
+
+def load_host_library():
+    global _host
+    if _host is not None:
+        return _host
+    path = os.path.join(_HERE, "host", "libpion_host.so")
+    if not os.path.exists(path):
+        raise ImportError("%s not found: build it with `make -C pion_amd/host`" % path)
+    abi.share_torch_hip_runtime()
+    h = C.CDLL(path)
+    h.pion_host_sim_create.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.POINTER(C.c_void_p)]
+    h.pion_host_sim_destroy.argtypes = [C.c_void_p]
+    h.pion_host_sim_destroy.restype = None
+    h.pion_host_sim_handle.argtypes = [C.c_void_p]
+    h.pion_host_sim_handle.restype = C.c_void_p
+    h.pion_host_sim_init.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_double]
+    h.pion_host_sim_time_int.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    h.pion_host_sim_step.argtypes = [C.c_void_p, _dp]
+    h.pion_host_sim_download.argtypes = [C.c_void_p, C.c_int, _dp]
+    h.pion_host_sim_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+    h.pion_host_sim_finish_halo.argtypes = [C.c_void_p]
+    h.pion_host_sim_last_error.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    h.pion_host_comm_unique_id.argtypes = [C.c_void_p]
+    h.pion_host_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    h.pion_host_comm_destroy.argtypes = [C.c_void_p]
+    h.pion_host_comm_destroy.restype = None
+    _host = h
+    return h
+
+
+def new_unique_id():
+    """ncclGetUniqueId on this rank (rank 0 calls it and broadcasts the 128 bytes)"""
+    buf = (C.c_char * UNIQUE_ID_BYTES)()
+    if load_host_library().pion_host_comm_unique_id(buf) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    return bytes(buf)
+
+
+class HostSim:
+    """pion_host::sim_control_gpu, optionally with a pion_host::slab_comm_rccl"""
+
+    def __init__(self, cfg, device=0, rank=0, world=1, periodic_z=True, unique_id=None):
+        self.lib = load_host_library()
+        self.cfg = cfg
+        self.s = C.c_void_p()
+        self.comm = C.c_void_p()
+        if self.lib.pion_host_sim_create(C.byref(cfg), device, C.byref(self.s)) != 0:
+            raise RuntimeError("pion_host_sim_create failed: " + self.last_error())
+        if unique_id is not None:
+            idb = (C.c_char * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+            if self.lib.pion_host_comm_create(rank, world, 1 if periodic_z else 0, idb, device, C.byref(self.comm)) != 0:
+                self.close()
+                raise RuntimeError("pion_host_comm_create failed")
+            rc = self.lib.pion_host_sim_set_comm(self.s, self.comm)
+            if rc != 0:
+                self.close()
+                raise RuntimeError("pion_host_sim_set_comm failed rc=%d" % rc)
+        nga = abi.ng_all(cfg)
+        self.shape = (cfg.nvar, nga[2], nga[1], nga[0])
+
+    def last_error(self):
+        buf = C.create_string_buffer(600)
+        self.lib.pion_host_sim_last_error(self.s, buf, 600)
+        return buf.value.decode(errors="replace")
+
+    def gpu_handle(self):
+        return self.lib.pion_host_sim_handle(self.s)
+
+    def init(self, P, simtime=0.0, finishtime=1e300, first_step_dt_limit=None):
+        Pc = np.ascontiguousarray(P, dtype=np.float64).reshape(-1)
+        rc = self.lib.pion_host_sim_init(self.s, Pc.ctypes.data_as(_dp), simtime, finishtime,
+                                         -1.0 if first_step_dt_limit is None else first_step_dt_limit)
+        if rc != 0:
+            raise RuntimeError("pion_host_sim_init rc=%d: %s" % (rc, self.last_error()))
+
+    def step(self):
+        dt = C.c_double()
+        rc = self.lib.pion_host_sim_step(self.s, C.byref(dt))
+        if rc != 0:
+            raise RuntimeError("pion_host_sim_step rc=%d: %s" % (rc, self.last_error()))
+        return dt.value
+
+    def finish_halo(self):
+        rc = self.lib.pion_host_sim_finish_halo(self.s)
+        if rc != 0:
+            raise RuntimeError("pion_host_sim_finish_halo rc=%d" % rc)
+
+    def time_int(self, nsteps):
+        t, ldt = C.c_double(), C.c_double()
+        n = self.lib.pion_host_sim_time_int(self.s, nsteps, C.byref(t), C.byref(ldt))
+        if n < 0:
+            raise RuntimeError("pion_host_sim_time_int: " + self.last_error())
+        return n, t.value, ldt.value
+
+    def download(self, which=0):
+        out = np.empty(int(np.prod(self.shape)))
+        rc = self.lib.pion_host_sim_download(self.s, which, out.ctypes.data_as(_dp))
+        if rc != 0:
+            raise RuntimeError("pion_host_sim_download rc=%d" % rc)
+        return out.reshape(self.shape)
+
+    def close(self):
+        # the communicator detaches its stream from the handle: destroy it first
+        if self.comm:
+            self.lib.pion_host_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
+        if self.s:
+            self.lib.pion_host_sim_destroy(self.s)
+            self.s = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -78,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "pion_gpu_set_glm_speeds", "pion_gpu_stage", "pion_gpu_advance_time", "pion_gpu_halo_count",
     "pion_gpu_pack_halo", "pion_gpu_unpack_halo", "pion_gpu_interface_flux",
     "pion_gpu_cooling_update", "pion_gpu_cooling_edot", "pion_gpu_enable_timing",
+    "pion_gpu_calc_dt_device", "pion_gpu_read_dt", "pion_gpu_get_stream",
     "pion_gpu_get_timing", "pion_gpu_stage_part", "pion_gpu_set_comm_stream", "pion_gpu_set_jet",
 ]
 
@@ -89,15 +90,21 @@ def _p(a):
 class GpuSim:
     """One pion_gpu handle (one GPU)."""
 
-    def __init__(self, cfg, device=0):
+    def __init__(self, cfg, device=0, borrowed_handle=None):
+        """borrowed_handle: wrap a handle that somebody else owns (pion_host::sim_control_gpu's, see
+        pion_amd/host_rccl.py) -- set-up calls and timing only; close() then leaves it alone."""
         self.lib = load_library()
         self.cfg = cfg
-        self.h = C.c_void_p()
-        rc = self.lib.pion_gpu_create(C.byref(cfg), device, C.byref(self.h))
-        if rc != 0:
-            msg = self._err() if self.h else "invalid configuration"
-            self.h = None
-            raise PionGpuError("create", rc, msg)
+        self.owner = borrowed_handle is None
+        if borrowed_handle is not None:
+            self.h = C.c_void_p(borrowed_handle)
+        else:
+            self.h = C.c_void_p()
+            rc = self.lib.pion_gpu_create(C.byref(cfg), device, C.byref(self.h))
+            if rc != 0:
+                msg = self._err() if self.h else "invalid configuration"
+                self.h = None
+                raise PionGpuError("create", rc, msg)
         self.nvar = cfg.nvar
         self.ncell = abi.ncell_all(cfg)
         nga = abi.ng_all(cfg)
@@ -114,7 +121,8 @@ class GpuSim:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.pion_gpu_destroy(self.h)
+            if self.owner:
+                self.lib.pion_gpu_destroy(self.h)
             self.h = None
 
     def __enter__(self):
