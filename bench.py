@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--eqn", default="glm", choices=["glm", "mhd"])
     ap.add_argument("--strict", type=int, default=0, help="1 = bit-parity kernels (no FMA contraction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not bracket the launches with HIP events (A/B of the event overhead; roofline fields are 0)")
     ap.add_argument("--no-parity-build", action="store_true", help="skip the strict-build throughput run")
     ap.add_argument("--cpu-n", type=int, default=64)
     ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3"],
@@ -290,7 +292,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sim.enable_timing(True)
+    if not args.no_kernel_timing:
+        sim.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

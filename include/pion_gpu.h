@@ -204,6 +204,12 @@ int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp);
  *   pion_gpu_read_dt         the single 16-byte read-back + the device error word. */
 int pion_gpu_calc_dt_device(void *handle, void **dptr);
 int pion_gpu_read_dt(void *handle, double *t_dyn, double *t_mp);
+/* pion_gpu_read_dt in two halves: _request enqueues the copy of the minima and of the error word into pinned
+ * host memory (compute stream) and returns; _wait blocks until it has arrived.  A host loop requests the
+ * minima right after the full-step stage, enqueues the boundary update and the halo exchange, and only then
+ * waits: the read-back latency hides under work the next step needs anyway. */
+int pion_gpu_dt_request(void *handle);
+int pion_gpu_dt_wait(void *handle, double *t_dyn, double *t_mp);
 
 /* FV_solver_mhd_mixedGLM_adi::Set_GLM_Speeds (solver_eqn_mhd_adi.cpp:906-922):
  * c_h = CFL*dx/dt, c_r = cr. */
@@ -242,6 +248,23 @@ int pion_gpu_advance_time(void *handle, double dt, double simtime);
  * (0=P,1=Ph) into a contiguous device buffer [nvar][nbc][ny_all][nx_all], or
  * write such a buffer into the ghost planes of that face. */
 long pion_gpu_halo_count(void *handle); /* doubles per halo buffer */
+/* In-place exchange (no pack / unpack kernels): in the [nvar][nz_all][ny_all][nx_all] layout the nbc planes
+ * next to a z face are ONE contiguous run of count_per_var doubles per variable, so a transport can send
+ * from, and receive into, the state array directly (variable v: pointer + v * var_stride doubles):
+ *   send_lo / send_hi  the first / last nbc on-grid planes (x/y ghosts included)
+ *   recv_lo / recv_hi  the ZN / ZP ghost planes.
+ * pion_gpu_halo_begin orders the communication stream after the compute stream's work so far (what
+ * pion_gpu_pack_halo does first), pion_gpu_halo_end marks the point of the communication stream after
+ * which the ghost planes are complete (what pion_gpu_unpack_halo does last): PION_STAGE_ZBOUNDARY and
+ * whole stages wait for it inside the library. */
+typedef struct {
+  double *send_lo, *send_hi, *recv_lo, *recv_hi;
+  long count_per_var, var_stride;
+  int nvar;
+} pion_gpu_halo_spans_t;
+int pion_gpu_halo_spans(void *handle, int which, pion_gpu_halo_spans_t *out);
+int pion_gpu_halo_begin(void *handle);
+int pion_gpu_halo_end(void *handle);
 int pion_gpu_pack_halo(void *handle, int which, int face, void *dbuf);
 int pion_gpu_unpack_halo(void *handle, int which, int face, void *dbuf);
 

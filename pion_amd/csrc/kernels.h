@@ -76,6 +76,7 @@ struct PrepassArgs {
   int eqntype, nvar, space_ooa;
   double gamma;
   long c0, c1;            // cell range [c0,c1) (whole planes) this launch covers
+  long c2, c3;            // k_prepass_hlld: a second range [c2,c3) in the same launch (empty when c3 <= c2)
 };
 
 struct DtArgs {

@@ -724,14 +724,17 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
   // range of (x,y,z) tiles (z slowest) so that the y and z neighbours it reads are lines its own L2 holds
   const long nc = a.g.ncell;
   const unsigned gx = (a.g.nga[0] + 63) / 64, gy = (a.g.nga[1] + 3) / 4;
-  const unsigned npl = (unsigned)((a.c1 - a.c0) / ((long)a.g.nga[0] * a.g.nga[1]));
+  const long plane = (long)a.g.nga[0] * a.g.nga[1];
+  const unsigned npl1 = (unsigned)((a.c1 - a.c0) / plane);
+  const unsigned npl = npl1 + ((a.c3 > a.c2) ? (unsigned)((a.c3 - a.c2) / plane) : 0u);
   const unsigned ntile = gx * gy * npl;
   const unsigned t = (unsigned)xcd_tile(blockIdx.x, ntile);
   if (t >= ntile) return;
   int i[3];
   i[0] = (int)((t % gx) * 64 + (threadIdx.x & 63));
   i[1] = (int)(((t / gx) % gy) * 4 + (threadIdx.x >> 6));
-  i[2] = (int)(a.c0 / ((long)a.g.nga[0] * a.g.nga[1])) + (int)(t / (gx * gy));
+  const unsigned pz = t / (gx * gy);
+  i[2] = (pz < npl1) ? (int)(a.c0 / plane) + (int)pz : (int)(a.c2 / plane) + (int)(pz - npl1);
   if (i[0] >= a.g.nga[0] || i[1] >= a.g.nga[1]) return;
   const long c = (long)i[0] + a.g.sy * i[1] + a.g.sz * i[2];
   const double dx = a.g.dx;
@@ -841,7 +844,7 @@ int launch_prepass(const PrepassArgs &a, hipStream_t s)
   if (a.hllflag) {
     // [c0,c1) is a whole number of planes (pion_gpu.hip)
     const long plane = (long)a.g.nga[0] * a.g.nga[1];
-    const unsigned npl = (unsigned)((a.c1 - a.c0) / plane);
+    const unsigned npl = (unsigned)((a.c1 - a.c0) / plane) + ((a.c3 > a.c2) ? (unsigned)((a.c3 - a.c2) / plane) : 0u);
     const unsigned ntile = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * npl;
     hipLaunchKernelGGL(k_prepass_hlld, dim3(((ntile + 7) / 8) * 8), dim3(256), 0, s, a);
   }

@@ -254,6 +254,9 @@ struct Handle {
   int *derr = nullptr;
   unsigned long long *ddt = nullptr;   // [0]=min t_dyn, [1]=min t_mp (bit patterns)
   unsigned long long *ddt_init = nullptr;  // {1e100, 1e99} on the device: reset source (no host buffer in flight)
+  double *hdt = nullptr;               // pinned host staging of {t_dyn, t_mp, error word} (pion_gpu_dt_request)
+  hipEvent_t ev_dt = nullptr;
+  bool dt_requested = false;
   std::vector<uint8_t> hflags;
   // boundary state
   double refval[6][PION_MAX_NVAR];
@@ -604,6 +607,8 @@ void pion_gpu_destroy(void *handle)
   hipFree(h->dflags);
   hipFree(h->dhll);
   hipFree(h->ddE);
+  if (h->hdt) hipHostFree(h->hdt);
+  if (h->ev_dt) hipEventDestroy(h->ev_dt);
   hipFree(h->deta);
   hipFree(h->dsphvol);
   hipFree(h->derr);
@@ -946,15 +951,40 @@ int pion_gpu_calc_dt_device(void *handle, void **dptr)
   return 0;
 }
 
-int pion_gpu_read_dt(void *handle, double *t_dyn, double *t_mp)
+int pion_gpu_dt_request(void *handle)
 {
   Handle *h = use(handle);
-  double out[2];
-  HCHECK(h, hipMemcpyAsync(out, h->ddt, sizeof out, hipMemcpyDeviceToHost, h->stream));
-  HCHECK(h, hipStreamSynchronize(h->stream));
-  *t_dyn = out[0];
-  *t_mp = out[1];
-  return check_errword(h);
+  if (!h->hdt) HCHECK(h, hipHostMalloc((void **)&h->hdt, 4 * sizeof(double), hipHostMallocDefault));
+  if (!h->ev_dt) HCHECK(h, hipEventCreateWithFlags(&h->ev_dt, hipEventDisableTiming));
+  // {min t_dyn, min t_mp} and the device error word, one event for both
+  HCHECK(h, hipMemcpyAsync(h->hdt, h->ddt, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHECK(h, hipMemcpyAsync(h->hdt + 2, h->derr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HCHECK(h, hipEventRecord(h->ev_dt, h->stream));
+  h->dt_requested = true;
+  return 0;
+}
+
+int pion_gpu_dt_wait(void *handle, double *t_dyn, double *t_mp)
+{
+  Handle *h = use(handle);
+  if (!h->dt_requested) {
+    h->err = "pion_gpu_dt_wait without pion_gpu_dt_request";
+    return PION_GPU_EINVAL;
+  }
+  HCHECK(h, hipEventSynchronize(h->ev_dt));
+  h->dt_requested = false;
+  *t_dyn = h->hdt[0];
+  *t_mp = h->hdt[1];
+  int e;
+  memcpy(&e, h->hdt + 2, sizeof e);
+  if (e) return check_errword(h);   // (re-reads and clears the word, builds the message)
+  return 0;
+}
+
+int pion_gpu_read_dt(void *handle, double *t_dyn, double *t_mp)
+{
+  if (int rc = pion_gpu_dt_request(handle)) return rc;
+  return pion_gpu_dt_wait(handle, t_dyn, t_mp);
 }
 
 int pion_gpu_calc_dt(void *handle, double *t_dyn, double *t_mp)
@@ -1015,6 +1045,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     // planes kz0-1 .. kz1; a whole stage covers every cell incl. ghosts like the reference's loop
     p.c0 = 0;
     p.c1 = h->g.ncell;
+    p.c2 = p.c3 = 0;
     if (!(first && last)) {
       const int nb = h->g.nbc[2], nz = h->g.ng[2];
       int lo = kz0 - 1, hi = kz1 + 1;        // on-grid plane numbers [lo,hi): the interior part
@@ -1029,15 +1060,14 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
       p.c0 = (long)(lo + nb) * h->g.sz;
       p.c1 = (long)(hi + nb) * h->g.sz;
     }
+    if (kz3 > kz2) {
+      // second strip (the upper z boundary): its own plane range of flags, same launch
+      const int nb = h->g.nbc[2], nz = h->g.ng[2];
+      p.c2 = (long)(nz - nb + 1 + nb) * h->g.sz;
+      p.c3 = (long)(nz + 1 + nb) * h->g.sz;
+    }
     time_begin(h, 1);
     rc = cfg.strict_fp ? fp_strict::launch_prepass(p, h->stream) : fp_fast::launch_prepass(p, h->stream);
-    if (rc == 0 && kz3 > kz2) {
-      // second strip (the upper z boundary): its own plane range of flags
-      const int nb = h->g.nbc[2], nz = h->g.ng[2];
-      p.c0 = (long)(nz - nb + 1 + nb) * h->g.sz;
-      p.c1 = (long)(nz + 1 + nb) * h->g.sz;
-      rc = cfg.strict_fp ? fp_strict::launch_prepass(p, h->stream) : fp_fast::launch_prepass(p, h->stream);
-    }
     time_end(h, 1);
     if (rc != 0) {
       h->err = "prepass launch failed";
@@ -1222,6 +1252,44 @@ static int halo_go(Handle *h, int which, int face, void *dbuf, int pack)
                      h->cfg.nvar, face, pack);
   HCHECK(h, hipGetLastError());
   if (cs != h->stream && !pack) {
+    if (!h->ev_unpacked) HCHECK(h, hipEventCreateWithFlags(&h->ev_unpacked, hipEventDisableTiming));
+    HCHECK(h, hipEventRecord(h->ev_unpacked, cs));
+    h->ev_unpacked_valid = true;
+  }
+  return 0;
+}
+int pion_gpu_halo_spans(void *handle, int which, pion_gpu_halo_spans_t *out)
+{
+  Handle *h = use(handle);
+  if (h->cfg.ndim != 3 || !out) return PION_GPU_EINVAL;
+  double *A = (which == 0) ? h->dP : h->dPh;
+  const long nb = h->g.nbc[2], nz = h->g.ng[2], sz = h->g.sz;
+  out->recv_lo = A;                       // ghost planes 0 .. nb-1
+  out->send_lo = A + nb * sz;             // first on-grid planes
+  out->send_hi = A + nz * sz;             // last on-grid planes (all-cell planes nz .. nz+nb-1)
+  out->recv_hi = A + (nz + nb) * sz;      // ghost planes nz+nb ..
+  out->count_per_var = nb * sz;
+  out->var_stride = h->g.ncell;
+  out->nvar = h->cfg.nvar;
+  return 0;
+}
+int pion_gpu_halo_begin(void *handle)
+{
+  Handle *h = use(handle);
+  hipStream_t cs = h->comm_stream ? h->comm_stream : h->stream;
+  if (cs != h->stream) {
+    // the planes to send were written (stage) and their x/y ghosts filled (BCs) on the compute stream
+    if (!h->ev_packed_src) HCHECK(h, hipEventCreateWithFlags(&h->ev_packed_src, hipEventDisableTiming));
+    HCHECK(h, hipEventRecord(h->ev_packed_src, h->stream));
+    HCHECK(h, hipStreamWaitEvent(cs, h->ev_packed_src, 0));
+  }
+  return 0;
+}
+int pion_gpu_halo_end(void *handle)
+{
+  Handle *h = use(handle);
+  hipStream_t cs = h->comm_stream ? h->comm_stream : h->stream;
+  if (cs != h->stream) {
     if (!h->ev_unpacked) HCHECK(h, hipEventCreateWithFlags(&h->ev_unpacked, hipEventDisableTiming));
     HCHECK(h, hipEventRecord(h->ev_unpacked, cs));
     h->ev_unpacked_valid = true;

@@ -57,6 +57,19 @@ int sim_control_gpu::stage(double dt, int space_ooa, int is_full)
 
 int sim_control_gpu::finish_halo() { return comm_ ? comm_->finish() : 0; }
 
+// The next step's time step depends on the state the full-step stage has just written (on-grid cells only,
+// so not on the boundary update that follows): start its reduction / read-back now, wait for it in
+// calculate_timestep -- the boundary kernels and the halo exchange are queued behind it meanwhile.
+int sim_control_gpu::request_next_dt()
+{
+  if (comm_) return comm_->request_min();
+  void *d = nullptr;
+  int err = pion_gpu_calc_dt_device(h_, &d);
+  if (!err) err = pion_gpu_dt_request(h_);
+  dt_requested_ = (err == 0);
+  return err;
+}
+
 int sim_control_gpu::Init(const double *P_soa, double simtime)
 {
   T.simtime = simtime;
@@ -71,7 +84,11 @@ int sim_control_gpu::calculate_timestep()
   double t_dyn = 0.0, t_mp = 0.0;
   // slab runs: the minima stay on the device until they are reduced over the ranks
   // (COMM->global_operation_double("MIN", .), sim_control_MPI.cpp:503-504)
-  int err = comm_ ? comm_->allreduce_min(&t_dyn, &t_mp) : pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
+  int err;
+  if (comm_) err = comm_->allreduce_min(&t_dyn, &t_mp);
+  else if (dt_requested_) err = pion_gpu_dt_wait(h_, &t_dyn, &t_mp);
+  else err = pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
+  dt_requested_ = false;
   if (err) return err;
   if (T.timestep == 0 && T.first_step_dt_limit > 0.0) t_dyn = std::min(t_dyn, T.first_step_dt_limit);
   T.dt = std::min(t_dyn, t_mp);
@@ -100,12 +117,14 @@ double sim_control_gpu::advance_time()
   int err = 0;
   if (cfg.tm_ooa == 1 && cfg.sp_ooa == 1) {
     err += first_order_update(T.dt, cfg.tm_ooa);
+    err += request_next_dt();
     err += update_boundaries(1, 1, 0);
   }
   else if (cfg.tm_ooa == 2 && cfg.sp_ooa == 2) {
     err += first_order_update(0.5 * T.dt, 2);
     err += update_boundaries(1, 2, 0);
     err += second_order_update(T.dt, 2);
+    err += request_next_dt();
     err += update_boundaries(2, 2, 0);
   }
   else throw std::runtime_error("Bad OOA requests; choose (1,1) or (2,2)");

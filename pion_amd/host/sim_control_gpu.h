@@ -52,6 +52,7 @@ class sim_control_gpu {
   int update_boundaries(int cstep, int maxstep, int assign);
   int stage(double dt, int space_ooa, int is_full);
   int finish_halo();
+  int request_next_dt();
 
   int download(int which, double *P_soa) { return pion_gpu_download(h_, which, P_soa); }
   void *handle() { return h_; }
@@ -63,6 +64,7 @@ class sim_control_gpu {
  private:
   void *h_;
   slab_comm_rccl *comm_ = nullptr;
+  bool dt_requested_ = false;
 };
 
 }  // namespace pion_host

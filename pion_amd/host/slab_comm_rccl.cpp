@@ -38,7 +38,7 @@ int slab_comm_rccl::get_unique_id(void *out128)
 
 slab_comm_rccl::slab_comm_rccl(int rank, int world, bool periodic_z, const void *unique_id, int device)
     : rank_(rank), world_(world), device_(device), up_(-1), down_(-1), comm_(nullptr), cstream_(nullptr), h_(nullptr),
-      send_up_(nullptr), send_down_(nullptr), recv_up_(nullptr), recv_down_(nullptr), count_(0), pending_(-1)
+      pending_(-1), requested_(false)
 {
   // decomposeDomain along z (MCMD_control.cpp:231-309): rank r is below r+1; periodic wrap 0 <-> world-1
   if (periodic_z || rank < world - 1) up_ = (rank + 1) % world;
@@ -61,10 +61,6 @@ slab_comm_rccl::~slab_comm_rccl()
     if (h_) (void)pion_gpu_set_comm_stream(h_, nullptr);
   }
   if (comm_) (void)ncclCommDestroy((ncclComm_t)comm_);
-  (void)hipFree(send_up_);
-  (void)hipFree(send_down_);
-  (void)hipFree(recv_up_);
-  (void)hipFree(recv_down_);
   if (cstream_) (void)hipStreamDestroy((hipStream_t)cstream_);
 }
 
@@ -72,12 +68,6 @@ int slab_comm_rccl::attach(void *gpu_handle)
 {
   h_ = gpu_handle;
   PH_HIP(hipSetDevice(device_));
-  count_ = pion_gpu_halo_count(h_);
-  const size_t nb = sizeof(double) * (size_t)count_;
-  PH_HIP(hipMalloc((void **)&send_up_, nb));
-  PH_HIP(hipMalloc((void **)&send_down_, nb));
-  PH_HIP(hipMalloc((void **)&recv_up_, nb));
-  PH_HIP(hipMalloc((void **)&recv_down_, nb));
   // a high-priority stream: the exchange must not queue behind the interior part of the stage
   int lo = 0, hi = 0;
   PH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -88,6 +78,10 @@ int slab_comm_rccl::attach(void *gpu_handle)
   return pion_gpu_set_comm_stream(h_, cstream_);
 }
 
+// The nbc planes next to a z face are one contiguous run per variable of the SoA state, so they are sent
+// from and received into the state array itself: no pack / unpack kernels, no staging buffers.  While the
+// transfer is in flight the compute stream runs the INTERIOR part of the next stage, which reads no z ghost
+// plane and writes the other array.
 int slab_comm_rccl::start(int which)
 {
   if (pending_ >= 0) {
@@ -100,19 +94,24 @@ int slab_comm_rccl::start(int which)
     return PION_GPU_EINVAL;
   }
   PH_HIP(hipSetDevice(device_));
-  int rc = 0;
-  // pack on the communication stream (the library orders it after the compute stream's work so far)
-  if (up_ >= 0 && (rc = pion_gpu_pack_halo(h_, which, 5, send_up_))) return rc;       // my top on-grid planes
-  if (down_ >= 0 && (rc = pion_gpu_pack_halo(h_, which, 4, send_down_))) return rc;   // my bottom on-grid planes
+  pion_gpu_halo_spans_t sp;
+  int rc = pion_gpu_halo_spans(h_, which, &sp);
+  if (rc) return rc;
+  if ((rc = pion_gpu_halo_begin(h_))) return rc;   // after the stage + boundary kernels that wrote the planes
   hipStream_t s = (hipStream_t)cstream_;
   ncclComm_t c = (ncclComm_t)comm_;
-  // one group: with two ranks and periodic z (or a rank that is its own neighbour) both messages go to
-  // the same peer and are matched in the order posted: first "top planes" -> the peer's ZN ghosts
+  const size_t n = (size_t)sp.count_per_var;
+  // one group; per variable: my top planes -> the upper neighbour's ZN ghosts, my bottom planes -> the lower
+  // neighbour's ZP ghosts.  With two ranks and periodic z (or a rank that is its own neighbour) every message
+  // goes to the same peer and is matched in the order posted, which is the same on both sides.
   PH_NCCL(ncclGroupStart());
-  if (up_ >= 0) PH_NCCL(ncclSend(send_up_, (size_t)count_, ncclDouble, up_, c, s));
-  if (down_ >= 0) PH_NCCL(ncclRecv(recv_down_, (size_t)count_, ncclDouble, down_, c, s));
-  if (down_ >= 0) PH_NCCL(ncclSend(send_down_, (size_t)count_, ncclDouble, down_, c, s));
-  if (up_ >= 0) PH_NCCL(ncclRecv(recv_up_, (size_t)count_, ncclDouble, up_, c, s));
+  for (int v = 0; v < sp.nvar; v++) {
+    const long o = (long)v * sp.var_stride;
+    if (up_ >= 0) PH_NCCL(ncclSend(sp.send_hi + o, n, ncclDouble, up_, c, s));
+    if (down_ >= 0) PH_NCCL(ncclRecv(sp.recv_lo + o, n, ncclDouble, down_, c, s));
+    if (down_ >= 0) PH_NCCL(ncclSend(sp.send_lo + o, n, ncclDouble, down_, c, s));
+    if (up_ >= 0) PH_NCCL(ncclRecv(sp.recv_hi + o, n, ncclDouble, up_, c, s));
+  }
   PH_NCCL(ncclGroupEnd());
   pending_ = which;
   return 0;
@@ -121,26 +120,34 @@ int slab_comm_rccl::start(int which)
 int slab_comm_rccl::finish()
 {
   if (pending_ < 0) return 0;
-  const int which = pending_;
   pending_ = -1;
   PH_HIP(hipSetDevice(device_));
-  int rc = 0;
-  // unpack is stream-ordered after the receives (same stream); the host does not wait
-  if (down_ >= 0 && (rc = pion_gpu_unpack_halo(h_, which, 4, recv_down_))) return rc;  // neighbour's top -> ZN ghosts
-  if (up_ >= 0 && (rc = pion_gpu_unpack_halo(h_, which, 5, recv_up_))) return rc;      // neighbour's bottom -> ZP ghosts
-  return 0;
+  // the ghost planes are complete once the communication stream has passed this point; the host does not wait
+  return pion_gpu_halo_end(h_);
 }
 
-int slab_comm_rccl::allreduce_min(double *t_dyn, double *t_mp)
+// enqueue: reduction of the device-resident {t_dyn, t_mp} over the ranks + copy to pinned host memory
+int slab_comm_rccl::request_min()
 {
   void *d = nullptr;
   if (int rc = pion_gpu_calc_dt_device(h_, &d)) return rc;
-  if (world_ > 1 || up_ >= 0) {
+  if (world_ > 1) {
     PH_HIP(hipSetDevice(device_));
     // in place, on the compute stream, behind the reduction kernel / the stage that left the minima
     PH_NCCL(ncclAllReduce(d, d, 2, ncclDouble, ncclMin, (ncclComm_t)comm_, (hipStream_t)pion_gpu_get_stream(h_, 0)));
   }
-  return pion_gpu_read_dt(h_, t_dyn, t_mp);
+  const int rc = pion_gpu_dt_request(h_);
+  requested_ = (rc == 0);
+  return rc;
+}
+
+int slab_comm_rccl::allreduce_min(double *t_dyn, double *t_mp)
+{
+  if (!requested_) {
+    if (int rc = request_min()) return rc;
+  }
+  requested_ = false;
+  return pion_gpu_dt_wait(h_, t_dyn, t_mp);
 }
 
 }  // namespace pion_host

@@ -10,9 +10,10 @@
 // ncclAllReduce(ncclMin) over the two doubles {t_dyn, t_mp} that the stage kernel left on the device;
 // the only host synchronisation per step is the 16-byte read-back of the reduced minima.
 //
-// The pack / unpack kernels and the stream ordering live behind the C-ABI (pion_gpu_pack_halo,
-// pion_gpu_unpack_halo, pion_gpu_set_comm_stream, pion_gpu_stage_part): this class owns the RCCL
-// communicator, the four halo buffers and the communication stream, nothing else.
+// The planes travel in place (pion_gpu_halo_spans: one contiguous run per variable and face, sent from and
+// received into the state arrays, no pack / unpack kernels); the stream ordering lives behind the C-ABI
+// (pion_gpu_halo_begin / _end, pion_gpu_set_comm_stream, pion_gpu_stage_part).  This class owns the RCCL
+// communicator and the communication stream, nothing else.
 #ifndef PION_SLAB_COMM_RCCL_H
 #define PION_SLAB_COMM_RCCL_H
 
@@ -34,8 +35,7 @@ class slab_comm_rccl {
 
   static int get_unique_id(void *out128);
 
-  // allocate the halo buffers for this handle, create the communication stream and register it
-  // (pion_gpu_set_comm_stream); must precede start()
+  // create the communication stream and register it (pion_gpu_set_comm_stream); must precede start()
   int attach(void *gpu_handle);
   // BC_update_BCMPI, first half: pack the on-grid planes next to the internal z faces of array `which`
   // (0 = P, 1 = Ph) and enqueue the grouped send / recv.  Returns at once.
@@ -43,7 +43,10 @@ class slab_comm_rccl {
   // second half: unpack into the ghost planes (communication stream; the library orders the
   // z-boundary part of the next stage after it)
   int finish();
-  // global minimum of the device-resident {t_dyn, t_mp} + the single read-back
+  // global minimum of the device-resident {t_dyn, t_mp}: request_min() enqueues the all-reduce and the copy
+  // to pinned host memory and returns (call it right after the full-step stage); allreduce_min() waits for
+  // it (requesting first if nobody has) -- the single host synchronisation of a step
+  int request_min();
   int allreduce_min(double *t_dyn, double *t_mp);
 
   bool has_neighbours() const { return up_ >= 0 || down_ >= 0; }
@@ -54,9 +57,8 @@ class slab_comm_rccl {
   void *comm_;      // ncclComm_t
   void *cstream_;   // hipStream_t
   void *h_;         // pion_gpu handle
-  double *send_up_, *send_down_, *recv_up_, *recv_down_;
-  long count_;
   int pending_;     // array of the exchange in flight, or -1
+  bool requested_;  // request_min() issued, allreduce_min() not yet
   std::string err_;
 };
 

@@ -68,7 +68,18 @@ class HostSim:
             raise RuntimeError("pion_host_sim_create failed: " + self.last_error())
         if unique_id is not None:
             idb = (C.c_char * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
-            if self.lib.pion_host_comm_create(rank, world, 1 if periodic_z else 0, idb, device, C.byref(self.comm)) != 0:
+            # RCCL prints a version banner on stdout when a communicator is created: send it to stderr
+            # (bench.py's stdout carries exactly one JSON line)
+            import sys
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                rc = self.lib.pion_host_comm_create(rank, world, 1 if periodic_z else 0, idb, device, C.byref(self.comm))
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
+            if rc != 0:
                 self.close()
                 raise RuntimeError("pion_host_comm_create failed")
             rc = self.lib.pion_host_sim_set_comm(self.s, self.comm)

@@ -78,7 +78,8 @@ EXPORTED_SYMBOLS = [
     "pion_gpu_set_glm_speeds", "pion_gpu_stage", "pion_gpu_advance_time", "pion_gpu_halo_count",
     "pion_gpu_pack_halo", "pion_gpu_unpack_halo", "pion_gpu_interface_flux",
     "pion_gpu_cooling_update", "pion_gpu_cooling_edot", "pion_gpu_enable_timing",
-    "pion_gpu_calc_dt_device", "pion_gpu_read_dt", "pion_gpu_get_stream",
+    "pion_gpu_calc_dt_device", "pion_gpu_read_dt", "pion_gpu_get_stream", "pion_gpu_dt_request", "pion_gpu_dt_wait",
+    "pion_gpu_halo_spans", "pion_gpu_halo_begin", "pion_gpu_halo_end",
     "pion_gpu_get_timing", "pion_gpu_stage_part", "pion_gpu_set_comm_stream", "pion_gpu_set_jet",
 ]
 
