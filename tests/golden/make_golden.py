@@ -19,6 +19,9 @@ Fixtures are data: seeded inputs and the reference's outputs, stored as compress
                     HLLD, GLM-MHD HLLD + tracer, GLM-MHD Roe first order).
   cell_kat.npz      CellAdvanceTime and CellTimeStep vectors (incl. negative-pressure repair,
                     with and without a microphysics object).
+  endstate.npz      long runs (`make_golden.py c`): low-resolution versions of BASELINE configs 1-4 (spherical 1-D
+                    Sedov n128, DMR 65 x 20 to t = 0.2, MHD blast 64 x 96 to t = 0.2 as GLM-MHD and as ideal MHD,
+                    3-D octant blast 32^3, 80 steps): every dt, the end state, the conserved totals.
   steps.npz         whole-grid dumps after 2 second-order steps (and per-stage aux data) for small
                     grids: HD Roe 3-D octant blast (reflecting/outflow), HD FVS 2-D with tracer,
                     HD Roe + H-correction 2-D, ideal-MHD HLLD 2-D periodic, GLM-MHD HLLD 3-D
@@ -124,9 +127,32 @@ def main():
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+def main_c():
+    """endstate.npz: low-resolution versions of BASELINE configs 1-4 run by the reference objects to their
+    finish time (or a fixed number of steps): every dt taken, the end state (on-grid and ghosts), the
+    conserved totals.  `make_golden.py c`."""
+    import time
+    out = {}
+    for name in gc.END_CASES:
+        cfg, P, tf, nmax = gc.end_case(name)
+        t0 = time.time()
+        with CpuSim(cfg, "ref") as r:
+            n, t, dts = gc.end_run(r, cfg, P, tf, nmax)
+            A = r.download(0)
+        tot, _ = gc.conserved_totals(cfg, A)
+        out[name + "_n"], out[name + "_t"], out[name + "_dt"] = np.array(n), np.array(t), dts
+        out[name + "_P"], out[name + "_tot"] = A, tot
+        print("%-22s %4d steps to t = %.6g  (%.1f s)" % (name, n, t, time.time() - t0))
+    np.savez_compressed(os.path.join(HERE, "endstate.npz"), **out)
+    print("endstate.npz", os.path.getsize(os.path.join(HERE, "endstate.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "b":
         main_b()
+    elif len(sys.argv) > 1 and sys.argv[1] == "c":
+        main_c()
     else:
         main()
         main_b()
+        main_c()

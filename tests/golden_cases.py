@@ -159,6 +159,109 @@ def step_case(name, strict_fp=1):
     raise KeyError(name)
 
 
+# ---- long runs: low-resolution versions of the BASELINE configurations, end state from the reference ----
+# (endstate.npz, made by `make_golden.py c`).  Parameter values are the shipped parameter files' (cited per
+# case); the initial data are our own closed forms of the same set-ups (no sub-cell blending), the same
+# arrays being fed to the reference objects, the oracle and the GPU.  Config 5 (Wind3D + cooling) is not
+# here: its cooling tables are "parity unpinned" (no GSL in the build container), see DESIGN.md s2.
+END_CASES = ["sph1d_n128", "dmr_n065", "mhd_bw2d_64x96", "mhd_ideal_bw2d_64x96", "bw3d_nr032"]
+
+
+def end_case(name, strict_fp=1):
+    """-> (cfg, P, finishtime, max_steps)"""
+    L = 30.86e18
+    if name == "sph1d_n128":
+        # test_problems/blastwave_sph1d/params_sphBW_n128.txt: spherical 1-D Euler, hybrid solver (3),
+        # 1e51 erg in BW_nzones = 1 cell, ambient 2.34e-22 / 1.38e-11, reflecting / outflow, CFL 0.3
+        n = 128
+        cfg = abi.make_config(1, [n], abi.EQEUL, abi.FLUX_RShybrid, artvisc=abi.AV_FKJ98_1D, etav=0.1, gamma=5.0 / 3.0,
+                              cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(L, 0.0, 0.0), bcs=["reflecting", "outflow"],
+                              refvec=[1.0e-23, 3.0e-10, 1.0e6, 1.0e6, 1.0e6], strict_fp=strict_fp, coord_sys=3)
+        P = problems.alloc(cfg)
+        X, _, _ = problems.mesh(cfg)
+        rb = 1.0 * cfg.dx
+        P[abi.RO] = 2.34e-22
+        P[abi.PG] = np.where(X < rb, 1.0e51 * (cfg.gamma - 1.0) / (4.0 / 3.0 * np.pi * rb ** 3), 1.38e-11)
+        return cfg, P, 1.58e12, 400
+    if name == "dmr_n065":
+        # test_problems/double_Mach_reflection/params_DMR_n065.txt: 65 x 20, Roe-CV (4), gamma 1.4, CFL 0.4, t = 0.2
+        cfg, P = problems.double_mach_reflection(65, strict_fp=strict_fp)
+        return cfg, P, 0.2, 2000
+    if name in ("mhd_bw2d_64x96", "mhd_ideal_bw2d_64x96"):
+        # test_problems/MHD_Blastwave2D/params_MHD_blastwave2D_UG_B010_n256.txt at 64 x 96: [-1/2,1/2] x
+        # [-3/4,3/4], periodic, HLLD (7), CFL 0.24, eta 0.1, t = 0.2; glm-mhd as shipped, and ideal MHD
+        eq = abi.EQGLM if name == "mhd_bw2d_64x96" else abi.EQMHD
+        cfg = abi.make_config(2, [64, 96], eq, abi.FLUX_RS_HLLD, artvisc=abi.AV_FKJ98_1D, etav=0.1, gamma=5.0 / 3.0,
+                              cfl=0.24, dx=1.0 / 64, xmin=(-0.5, -0.75, 0.0), bcs=["periodic"] * 4,
+                              refvec=[1.0, 0.1, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], strict_fp=strict_fp)
+        P = problems.alloc(cfg)
+        X, Y, _ = problems.mesh(cfg)
+        P[abi.RO] = 1.0
+        P[abi.PG] = np.where(X * X + Y * Y < 0.01, 10.0, 0.1)
+        P[abi.BX] = 1.0 / np.sqrt(2.0)
+        P[abi.BY] = 1.0 / np.sqrt(2.0)
+        return cfg, P, 0.2, 2000
+    if name == "bw3d_nr032":
+        # test_problems/blastwave_crt3d/params_BWcrt3D_Octant_NR032.txt: 32^3 octant, Roe-CV (4), 1e51 erg in
+        # BW_nzones = 2 cells, ambient 2.34e-22 / 1.38e-11, reflecting / outflow, CFL 0.3; the first 80 steps
+        bcs = ["reflecting", "outflow"] * 3
+        cfg = abi.make_config(3, [32, 32, 32], abi.EQEUL, abi.FLUX_RSroe, artvisc=abi.AV_FKJ98_1D, etav=0.1,
+                              gamma=5.0 / 3.0, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(L, L, L), bcs=bcs,
+                              refvec=[1.0e-23, 3.0e-10, 1.0e6, 1.0e6, 1.0e6], strict_fp=strict_fp)
+        P = problems.alloc(cfg)
+        X, Y, Z = problems.mesh(cfg)
+        rb = 2.0 * cfg.dx
+        P[abi.RO] = 2.34e-22
+        P[abi.PG] = np.where(X * X + Y * Y + Z * Z < rb * rb, 1.0e51 * (cfg.gamma - 1.0) / (4.0 / 3.0 * np.pi * rb ** 3),
+                             1.38e-11)
+        return cfg, P, 1.58e12, 80
+    raise KeyError(name)
+
+
+def end_run(sim, cfg, P, finishtime, max_steps):
+    """the time loop of sim_control::Time_Int on any backend -> (steps taken, end time, list of dt)"""
+    from pion_amd import driver
+    sc = driver.SimControl(sim, cfg, finishtime=finishtime)
+    sc.init(P)
+    dts = []
+    while sc.simtime < finishtime and len(dts) < max_steps:
+        dts.append(sc.calculate_timestep())
+        sc.advance_time()
+    sc.finish_halo()
+    return len(dts), sc.simtime, np.array(dts)
+
+
+def conserved_totals(cfg, A):
+    """sums over the on-grid cells of rho, rho v, E (and B): the BASELINE conservation gate"""
+    nb = cfg.nbc
+    sl = [slice(None)] + [slice(nb, -nb) if a < cfg.ndim else slice(None) for a in (2, 1, 0)]
+    q = A[tuple(sl)]
+    ro, pg, v = q[0], q[1], q[2:5]
+    E = pg / (cfg.gamma - 1.0) + 0.5 * ro * (v ** 2).sum(axis=0)
+    vals = [ro, ro * v[0], ro * v[1], ro * v[2]]
+    if cfg.eqntype != abi.EQEUL:
+        B = q[5:8]
+        E = E + 0.5 * (B ** 2).sum(axis=0)
+        vals += [B[0], B[1], B[2]]
+    vals.append(E)
+    return np.array([x.sum() for x in vals]), np.array([np.abs(x).sum() for x in vals])
+
+
+def on_grid(cfg, A):
+    nb = cfg.nbc
+    sl = [slice(None)] + [slice(nb, -nb) if a < cfg.ndim else slice(None) for a in (2, 1, 0)]
+    return A[tuple(sl)]
+
+
+def diff_norms(cfg, a, b):
+    """per-variable L1 / L2 / max of a-b over the on-grid cells, in units of refvec
+    (the norms of analysis/silocompare/silocompare.cpp:371-430)"""
+    nv = cfg.nvar
+    d = np.abs(on_grid(cfg, a) - on_grid(cfg, b)).reshape(nv, -1)
+    rv = np.array([cfg.refvec[v] for v in range(nv)])
+    return d.mean(axis=1) / rv, np.sqrt((d * d).mean(axis=1)) / rv, d.max(axis=1) / rv
+
+
 # ---- cooling ODE known-answer test -------------------------------------------------------------
 ODE_TMIN, ODE_TMAX, ODE_NT = 1.0e2, 1.0e8, 200
 ODE_GAMMA = 5.0 / 3.0
