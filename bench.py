@@ -27,6 +27,19 @@ from pion_amd import abi, driver, lib, problems, slab  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def kernel_source_hash():
+    """hash of pion_amd/csrc sources (the same function as profiles/tools/summarize_r02.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pion_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")) or f == "Makefile":
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def baseline_metric():
     """BASELINE.json's metric string, verbatim (the file travels with the repo)"""
     try:
@@ -36,12 +49,47 @@ def baseline_metric():
         return "Mcell-updates/s on 3D ideal-MHD 512\u00b3 uniform grid; achieved HBM GB/s vs peak"
 
 
-def _time_cpu(kind, n, eqntype, solver, budget_s):
+def _cpu_case(workload, ng, eqn):
+    """the benchmark workloads on an ng[0] x ng[1] x ng[2] grid (CPU baselines; strict arithmetic)"""
+    if workload == "m1":
+        eq = abi.EQGLM if eqn == "glm" else abi.EQMHD
+        cfg, _ = problems.mhd_blastwave(4, 3, eq, abi.FLUX_RS_HLLD, strict_fp=1)
+        for a in range(3):
+            cfg.ng[a] = ng[a]
+        cfg.dx = 1.0 / ng[0]
+        return cfg, problems.fill_mhd_blastwave(cfg), None, None
+    if workload == "m2":
+        cfg, _ = problems.hd_blast_octant(4, 3, solver=abi.FLUX_RSroe, strict_fp=1)
+        L = cfg.dx * 4
+        for a in range(3):
+            cfg.ng[a] = ng[a]
+        cfg.dx = L / ng[0]
+        return cfg, problems.fill_hd_blast_octant(cfg, ng[0] / 32.0), None, None
+    cfg, _, _, _ = problems.wind3d(8, strict_fp=1)
+    L = cfg.dx * 8
+    for a in range(3):
+        cfg.ng[a] = ng[a]
+    cfg.dx = L / ng[0]
+    P, wind, dt_lim = problems.fill_wind3d(cfg, ng[0])
+    return cfg, P, wind, dt_lim
+
+
+def cpu_worker(spec):
+    """`bench.py --cpu-worker kind,workload,eqn,nx,ny,nz,budget_s`: one CPU process of the baseline (started by
+    cpu_baseline() BEFORE or beside the GPU work, never touches the GPU).  Prints one JSON line."""
+    kind, workload, eqn, nx, ny, nz, budget = spec.split(",")
+    ng, budget = [int(nx), int(ny), int(nz)], float(budget)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_backends import CpuSim
-    cfg, P = problems.mhd_blastwave(n, 3, eqntype, solver, strict_fp=1)
+    cfg, P, wind, dt_lim = _cpu_case(workload, ng, eqn)
     with CpuSim(cfg, kind) as o:
+        if wind is not None:
+            from pion_amd import cooling
+            o.set_cooling_tables(*cooling.build_tables(cfg.min_temp, cfg.max_temp))
+            if wind[0].size:
+                o.set_wind_cells(*wind)
         sc = driver.SimControl(o, cfg)
+        sc.first_step_dt_limit = dt_lim
         sc.init(P)
         sc.calculate_timestep()
         sc.advance_time()  # untimed first step
@@ -52,33 +100,73 @@ def _time_cpu(kind, n, eqntype, solver, budget_s):
             sc.advance_time()
             steps += 1
             el = time.perf_counter() - t0
-            if el > budget_s or steps >= 50:
+            if el > budget or steps >= 200:
                 break
-    return n ** 3 * steps / el / 1e6, steps, el
+    print(json.dumps({"cells": ng[0] * ng[1] * ng[2], "steps": steps, "seconds": el}))
 
 
-def cpu_baseline(n, eqntype, solver, budget_s=12.0):
-    """CPU baseline on the same problem shrunk to n^3, one thread, a bounded number of steps.
-    kind "reference": oracle/_ref/libpion_ref.so -- the reference's own solver objects (compiled from
-    /root/reference in the build container by `make -C oracle ref`; the .so travels with the snapshot)
-    driven by oracle/ref_harness.cpp's restatement of the time_integrator loops -- when it is present;
-    otherwise kind "port": the scalar oracle (oracle/liboracle.so).  The other one is reported beside it."""
+def _run_cpu_workers(specs):
+    """start one process per spec at once, wait for all -> list of their JSON results"""
+    import subprocess
+    env = dict(os.environ)
+    env["PION_NO_TORCH"] = "1"
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", sp], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, env=env, text=True) for sp in specs]
+    out = []
+    for p in procs:
+        so, _ = p.communicate()
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
+        out.append(json.loads(lines[-1]) if (p.returncode == 0 and lines) else None)
+    return out
+
+
+def cpu_baseline(n, eqn, budget_s=10.0):
+    """CPU baselines of SURVEY 8(d) on this box's host cores (the reference has no threads: "N cores" = N
+    processes):
+      value        M1 on ALL cores: one process per core, each a z-slab n x n x (n/C) of the n^3 problem,
+                   run as C independent periodic slabs (no halo exchange between them: an upper bound on an MPI
+                   run of the same decomposition); sum of the processes' rates
+      single_core  the same problem, n^3, one process
+      m2 / m3      single-core rates of the other two workloads at 48^3 (m3: cooling tables are not in
+                   oracle/_ref -- GSL -- so that one is the oracle, kind "port")
+    kind "reference": oracle/_ref/libpion_ref.so (the reference's own solver objects, -O3 -DSERIAL, under
+    oracle/ref_harness.cpp's time_integrator loops) when it is present, else kind "port": oracle/liboracle.so."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_backends import have_oracle, have_ref
-    res = {}
-    if have_ref():
-        res["reference"] = _time_cpu("ref", n, eqntype, solver, budget_s)
-    if have_oracle():
-        res["port"] = _time_cpu("orc", n, eqntype, solver, budget_s)
-    if not res:
+    if not (have_ref() or have_oracle()):
         return None
-    kind = "reference" if "reference" in res else "port"
-    v, steps, el = res[kind]
-    lib = "oracle/_ref/libpion_ref.so (reference objects, -O3 -DSERIAL)" if kind == "reference" else "oracle/liboracle.so"
-    out = {"value": v, "unit": "Mcell-updates/s", "cores": 1, "kind": kind,
-           "sample": "%d steps of the same GLM-MHD HLLD blast on %d^3 (%.1f s, 1 thread, %s)" % (steps, n, el, lib)}
-    if kind == "reference" and "port" in res:
-        out["port_value"] = res["port"][0]
+    kind = "ref" if have_ref() else "orc"
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    C = 1
+    while C * 2 <= min(cores, 64) and n % (C * 2) == 0 and n // (C * 2) >= 4:
+        C *= 2
+    rate = lambda r: r["cells"] * r["steps"] / r["seconds"] / 1e6
+    res_all = _run_cpu_workers(["%s,m1,%s,%d,%d,%d,%g" % (kind, eqn, n, n, n // C, budget_s)] * C)
+    if any(r is None for r in res_all):
+        return None
+    singles = _run_cpu_workers(["%s,m1,%s,%d,%d,%d,%g" % (kind, eqn, n, n, n, budget_s),
+                                "orc,m1,%s,%d,%d,%d,%g" % (eqn, n, n, n, budget_s),
+                                "%s,m2,%s,48,48,48,%g" % (kind, eqn, 0.6 * budget_s),
+                                "orc,m3,%s,48,48,48,%g" % (eqn, 0.6 * budget_s)])
+    lib = "oracle/_ref/libpion_ref.so (reference objects, -O3 -DSERIAL)" if kind == "ref" else "oracle/liboracle.so"
+    out = {"value": sum(rate(r) for r in res_all), "unit": "Mcell-updates/s", "cores": C,
+           "kind": "reference" if kind == "ref" else "port",
+           "sample": "M1 (GLM-MHD HLLD blast) %d^3 as %d independent periodic z-slabs %dx%dx%d, one process per core, "
+                     "%d-%d steps each in %.0f s; %s; host has %d cores available" % (
+                         n, C, n, n, n // C, min(r["steps"] for r in res_all), max(r["steps"] for r in res_all),
+                         max(r["seconds"] for r in res_all), lib, cores)}
+    if singles[0]:
+        out["single_core_value"] = rate(singles[0])
+    if singles[1]:
+        out["port_value"] = rate(singles[1])
+    if singles[2]:
+        out["m2_single_core"] = {"value": rate(singles[2]), "kind": out["kind"], "sample": "M2 Euler Roe-CV octant blast 48^3"}
+    if singles[3]:
+        out["m3_single_core"] = {"value": rate(singles[3]), "kind": "port",
+                                 "sample": "M3 Wind3D FVS + cooling 48^3 (oracle: cooling tables are parity-unpinned)"}
     return out
 
 
@@ -119,6 +207,8 @@ def parity_build_run(args, cfg, device, dt_lim, steps=3, warmup=1):
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -130,7 +220,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the launches with HIP events (A/B of the event overhead; roofline fields are 0)")
     ap.add_argument("--no-parity-build", action="store_true", help="skip the strict-build throughput run")
-    ap.add_argument("--cpu-n", type=int, default=64)
+    ap.add_argument("--cpu-n", type=int, default=128, help="cells per axis of the CPU baseline sample")
     ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3"],
                     help="m1 (default, the headline): MHD blast; m2: 3-D Euler Roe-CV octant Sedov blast (SURVEY 8d); "
                          "m3: Wind3D single level, FVS + cooling 8 + stellar wind (single GPU).  m2/m3 are extra rows for "
@@ -292,15 +382,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if not args.no_kernel_timing:
-        sim.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     el = time.perf_counter() - t0
-    tm = sim.get_timing()
+    # kernel durations for the roofline: HIP events around every launch, on the stream it is launched on, over
+    # a few MORE steps after the timed region (event records between dependent kernels on two streams cost
+    # ~0.5 ms per step in the slab path, so they stay out of `value`)
+    ev_steps = 0
+    tm = {"stage_ms": 0.0, "stage_n": 0, "prepass_ms": 0.0, "bc_ms": 0.0, "dt_ms": 0.0}
+    if not args.no_kernel_timing:
+        ev_steps = max(1, min(3, args.steps))
+        sim.enable_timing(True)
+        for _ in range(ev_steps):
+            step()
+        barrier()
+        tm = sim.get_timing()
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda" if (args.backend == "nccl" and hs is None) else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -315,31 +414,37 @@ def main():
         cells_rank = cfg.ng[0] * cfg.ng[1] * cfg.ng[2]
         alg_bytes = 2.5 * nvar * 8 * cells_rank
         # (N > 1 splits a stage into interior + 2 z-boundary launches: sum them per stage)
-        stage_ms = tm["stage_ms"] * tm["stage_n"] / (2.0 * args.steps)
+        stage_ms = tm["stage_ms"] * tm["stage_n"] / (2.0 * ev_steps) if ev_steps else 0.0
         achieved = alg_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
-        # HBM-side bytes per stage launch from the PMC passes of this same command (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction calibrated on 8 B/lane
-        # accesses): profiles/r01_pmc_traffic.json, written by profiles/tools/summarize_r01.py.
-        # Counters cannot be read from inside this process, so the committed measurement is quoted
-        # when it is for this workload (512^3, GLM, fast mode, 1 GPU); otherwise null.
+        # Bytes per stage launch that left L2, from the PMC passes of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction calibrated on 8 B/lane accesses):
+        # profiles/r02_pmc_traffic.json, written by profiles/tools/summarize_r02.py.  Counters cannot be read
+        # from inside this process, so the committed measurement is quoted -- only for the workload it was
+        # taken on (512^3, GLM, fast mode, 1 GPU) and only while the kernel sources still hash to what it was
+        # taken on; otherwise null.
         traffic = None
-        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if (world == 1 and not loopback and n == 512 and eq == abi.EQGLM and not args.strict and args.workload == "m1"
-                and os.path.exists(tfile)):
-            with open(tfile) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
-        # where the time goes, from the committed SQ counter pass of this command (the kernel is fp64-VALU
-        # and latency bound, not HBM bound): instructions per launch, share of wave cycles issuing VALU /
-        # parked on s_waitcnt
         valu = None
-        sfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_sq_stage_kernel.json")
-        if traffic is not None and os.path.exists(sfile):
-            with open(sfile) as f:
-                c = json.load(f)["counters"]
-            valu = {"valu_insts_per_launch": c["SQ_INSTS_VALU"],
-                    "valu_active_frac_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
-                    "waitcnt_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                    "source": "profiles/r01_pmc_sq_stage_kernel.json"}
+        pdir = os.path.join(ROOT, "profiles")
+        tfile, sfile = os.path.join(pdir, "r02_pmc_traffic.json"), os.path.join(pdir, "r02_pmc_sq_stage_kernel.json")
+        if (world == 1 and not loopback and n == 512 and not args.nz and eq == abi.EQGLM and not args.strict
+                and args.workload == "m1"):
+            src = kernel_source_hash()
+            if os.path.exists(tfile):
+                with open(tfile) as f:
+                    t = json.load(f)
+                if t.get("kernel_source_hash") == src:
+                    traffic = t.get("traffic_bytes_per_launch")
+            # where the time goes (the kernel is fp64-VALU bound, not HBM bound): instructions per launch,
+            # share of wave cycles issuing VALU / parked on s_waitcnt, from the committed SQ counter pass
+            if os.path.exists(sfile):
+                with open(sfile) as f:
+                    t = json.load(f)
+                if t.get("kernel_source_hash") == src:
+                    c = t["counters"]
+                    valu = {"valu_insts_per_launch": c["SQ_INSTS_VALU"],
+                            "valu_active_frac_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                            "waitcnt_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                            "waves_per_simd": 2, "source": "profiles/r02_pmc_sq_stage_kernel.json"}
         out = {
             "metric": baseline_metric(),
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
@@ -353,15 +458,18 @@ def main():
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                         "step_frac": value * 1e6 * 5 * nvar * 8 / (HBM_PEAK_GBS * 1e9 * world),
+                         "step_frac_what": "SURVEY 8(d): whole-step rate x 5 nvar 8 B per cell-update / (peak x GPUs): "
+                                           "prepass, boundary and reduction launches included",
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r02_pmc_traffic.json; null when the kernel sources have changed since)",
                          "kernel": {"m1": "k_stage_rows2<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows2<MHD,0,HLLD>",
                                     "m2": "k_stage_rows2<EUL,0,Roe-CV>", "m3": "k_stage_rows2<EUL,1,FVS>"}[args.workload]
                                    + " (first-order + second-order instance, mean per launch)",
-                         "kernel_ms": stage_ms, "launches_per_stage": tm["stage_n"] / (2.0 * args.steps), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
+                         "kernel_ms": stage_ms, "kernel_ms_from": "HIP events over %d steps after the timed region" % ev_steps, "launches_per_stage": (tm["stage_n"] / (2.0 * ev_steps) if ev_steps else 0.0), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes, "issue": valu},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "m1":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, eq, solver)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.eqn)
         if world == 1 and not loopback and not args.strict and not args.no_parity_build:
             # the same workload through the PARITY build (strict_fp=1: -ffp-contract=off, the reference's
             # operation order, bit-identical to the oracle): its throughput beside the headline
