@@ -577,9 +577,7 @@ static int cooling_go(const StageArgs &a, hipStream_t s)
 template <int EQ, int NTR, int SOLVER>
 static int stage_go(const StageArgs &a, hipStream_t s)
 {
-  if (a.use_march == 3 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_rows2_go<EQ, NTR, SOLVER>(a, s);
-  if (a.use_march == 2 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_rows_go<EQ, NTR, SOLVER>(a, s);
-  if (a.use_march == 1 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_march_go<EQ, NTR, SOLVER>(a, s);
+  if (a.use_march != 0 && a.g.ndim == 3 && a.g.nbc[2] >= 2) return stage_rows2_go<EQ, NTR, SOLVER>(a, s);
   const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
   const long ntiles = (long)nbx * nby * a.g.ng[2];
   const long nblocks = ((ntiles + 7) / 8) * 8;

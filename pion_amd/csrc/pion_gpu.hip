@@ -421,7 +421,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   Handle *h = new Handle;
   h->cfg = *cfg;
   if (const char *e = getenv("PION_STAGE_KERNEL"))
-    h->use_march = (strcmp(e, "cell") == 0) ? 0 : ((strcmp(e, "march") == 0) ? 1 : ((strcmp(e, "rows1") == 0) ? 2 : 3));
+    h->use_march = (strcmp(e, "cell") == 0) ? 0 : 3;
   if (const char *e = getenv("PION_ZSLOPE_LDS")) h->zslope_lds = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
@@ -1122,16 +1122,12 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     // minimises it.
     const int nv = cfg.nvar;
     int rows = a.rows;
-    if (a.use_march != 3) {
-      const int rmax = (int)((160 * 1024) / (sizeof(double) * 4 * (2 * nv) * 64));
-      if (rows > rmax) rows = rmax;
-    }
     if (rows < 1) rows = 1;
     const int nyg = (h->g.ng[1] + rows - 1) / rows;
     const int ntx_full = h->g.ng[0] / 62, rem = h->g.ng[0] - ntx_full * 62;
     const int spw = (rem > 0) ? 64 / (rem + 2) : 0;
     const long per_chunk = (long)ntx_full * nyg + ((rem > 0) ? (nyg + spw - 1) / spw : 0);
-    const long slots = ((a.use_march == 3) ? 8L : 4L) * (h->ncu > 0 ? h->ncu : 256);
+    const long slots = 8L * (h->ncu > 0 ? h->ncu : 256);   // two workgroups of four wavefronts per CU
     const int np = kz1 - kz0;
     long best_cost = -1;
     a.zchunk = 8;

@@ -1,29 +1,14 @@
-// stage_rows.h -- k_stage_rows: the 3-D production stage kernel.
+// stage_rows.h -- x/y tiling of one plane chunk of the 3-D stage kernel (k_stage_rows2, stage_rows2.h),
+// shared by the kernel and its launcher.
 //
-// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after stage_march.h, whose helpers
-// load_rot / slope3 / apply_axis / cell_update_store it reuses).
-//
-// Same dataflow as k_stage_march (one wavefront per x-pencil of 64 lanes, marching along z, x fluxes
-// shared by wavefront shuffles) with what the profiles asked for:
-//   * a wavefront owns R consecutive y-rows and visits them one after the other inside each
-//     z-plane, carrying the flux through the upper y face (and the slope of the next row) to the
-//     next row in registers: (3R+1)/R Riemann solves per cell instead of 4;
-//   * the z-carried state (slope of the current plane, flux through the lower z face) of every
-//     row lives in LDS ([row][var][lane], conflict-free 8-byte accesses), not in registers;
-//   * loads are ordered for the one wavefront a SIMD holds (in-order return): what a task needs at
-//     once first, then the rows that come from HBM, requested a Riemann solve ahead of their use;
-//   * the remainder of a row that does not fill a 62-cell tile shares a wavefront with the
-//     remainders of the next row groups (RowsTiling);
-//   * the production instances are specialised at compile time (OAMODE, PLAIN; stage_rows_go);
-//   * on a second-order full step the kernel leaves the next time step's minima behind (dtres).
-// It still runs one wavefront per SIMD (256 VGPR + AGPRs).  The arithmetic and its order are the
-// reference's (the strict build stays bit-identical to the oracle).
+// x: full tiles of PION_MARCH_XT = 62 cells, one wavefront each (lanes 0 and 63 are halo lanes that only
+// supply their neighbour's interface data).  The remaining `rem` cells of a row (16 of 512) would leave most
+// of a wavefront idle, so a "remainder" wavefront packs the remainders of `spw` consecutive row groups side by
+// side, each in a segment of rem + 2 lanes with its own two halo lanes (the x shuffles only ever cross a segment
+// boundary into a halo lane).  y: groups of a.rows consecutive rows per wavefront.
 #ifndef PION_STAGE_ROWS_H
 #define PION_STAGE_ROWS_H
 
-#ifndef PION_ROWS_ATTR
-#define PION_ROWS_ATTR
-#endif
 // x/y tiling of one plane chunk, shared by the kernel and its launcher
 struct RowsTiling {
   int ntx_full, rem, spw, nyg, nfull, nrem, per_chunk;
@@ -39,516 +24,6 @@ __host__ __device__ inline RowsTiling rows_tiling(const StageArgs &a)
   t.nrem = (t.rem > 0) ? (t.nyg + t.spw - 1) / t.spw : 0;
   t.per_chunk = t.nfull + t.nrem;
   return t;
-}
-
-template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN>
-__global__ __launch_bounds__(256) PION_ROWS_ATTR void k_stage_rows(const StageArgs a)
-{
-  typedef Eqn<EQ, NTR> E;
-  typedef Flux<EQ, NTR, SOLVER> FX;
-  constexpr int NV = E::NV;
-  constexpr bool MHD = E::MHD;
-  extern __shared__ double lds[];
-
-  const int R = a.rows;
-  // x tiling: full tiles of PION_MARCH_XT cells, one wavefront each; the remaining rem cells of a row
-  // (16 of 512) would leave most of a wavefront idle, so a "remainder" wavefront packs the remainders
-  // of spw consecutive row groups side by side, each in a segment of rem+2 lanes with its own two
-  // halo lanes (the x shuffles only ever cross a segment boundary into a halo lane)
-  const RowsTiling tl = rows_tiling(a);
-  const int nyg = tl.nyg;
-  const int nzc1 = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
-  const int nzc = nzc1 + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;   // chunks of both strips
-  const long ntiles = (long)tl.per_chunk * nzc;
-  // PION_WAVE_UNIFORM (strict build, see Makefile): readfirstlane tells the compiler the wavefront
-  // number -- and the tile, row and plane loops that follow from it -- is uniform, so they live in SGPRs
-  // and branch on the scalar unit.  Measured 1 ms/launch slower at 512^3 (more SGPR spill traffic), so
-  // the fast build keeps the vector form.
-#ifdef PION_WAVE_UNIFORM
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#else
-  const int wave = threadIdx.x >> 6;
-#endif
-  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
-  if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
-  const int cz = (int)(tile / tl.per_chunk), tt = (int)(tile % tl.per_chunk);
-  const int lane = threadIdx.x & 63;
-  int ix, jg, jg_first;   // jg: this LANE's row group; jg_first: the wavefront's first (uniform)
-  bool writer;
-  if (tt < tl.nfull) {
-    const int tx = tt % tl.ntx_full;
-    jg = jg_first = tt / tl.ntx_full;
-    ix = tx * PION_MARCH_XT - 1 + lane;
-    writer = (lane >= 1 && lane <= PION_MARCH_XT && ix < a.g.ng[0]);
-  }
-  else {
-    const int seg = lane / (tl.rem + 2), pos = lane % (tl.rem + 2);
-    jg_first = (tt - tl.nfull) * tl.spw;
-    jg = jg_first + seg;
-    ix = tl.ntx_full * PION_MARCH_XT - 1 + pos;
-    writer = (seg < tl.spw && jg < nyg && pos >= 1 && pos <= tl.rem);
-    if (jg >= nyg) jg = nyg - 1;   // idle lanes redo the last group, in bounds, and write nothing
-  }
-  if (ix > a.g.ng[0]) ix = a.g.ng[0];
-  const int j0 = jg * R;
-  // rows of the wavefront's first group (the longest: only the last group of a plane can be short) bound
-  // the row loop; a lane whose own group is shorter repeats its last row (rr) and is masked out (row_ok)
-  const int nrows = (jg_first * R + R <= a.g.ng[1]) ? R : a.g.ng[1] - jg_first * R;
-  const int nrows_l = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
-  const int k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
-  const int kend = (cz < nzc1) ? a.kz1 : a.kz3;
-  const int k1 = (k0 + a.zchunk < kend) ? k0 + a.zchunk : kend;
-
-  const long nc = a.g.ncell, sy = a.g.sy, sz = a.g.sz;
-  const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
-  // OAMODE 1 / 2: the spatial order is known at compile time, so that the first-order stage (the half
-  // step of every second-order step) drops the slope arithmetic, the +-2 stencil rows and their
-  // registers: 24.1 -> 21.3 ms per launch at 512^3.  OAMODE 0: read from the arguments (the form every
-  // instance was validated in; specialised instances are only built where they are exercised and
-  // tested, see stage_rows_go).
-  const bool oa2 = (OAMODE == 0) ? (a.space_ooa == 2) : (OAMODE == 2);
-  // PLAIN: no H-correction, no cooling / microphysics object -- known at compile time (the common
-  // production case), so their code and registers disappear
-  const bool hcorr = PLAIN ? false : (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
-  FluxCtx fc = a.fc;
-  if (PLAIN) fc.mp.present = 0;
-  int err = 0;
-  double tdyn = 1.e100, tmp = 1.0e99;  // running minima for the fused time-step reduction
-
-  // this wavefront's LDS: zst[row][slot][lane], slot 0..NV-1 = z slope, NV..2NV-1 = lower z flux
-  const int zbase = wave * R * (2 * NV) * 64 + lane;
-#define ZS(r, s) lds[zbase + ((r) * (2 * NV) + (s)) * 64]
-
-  const long crow0 = (long)(ix + a.g.nbc[0]) + sy * (j0 + a.g.nbc[1]) + sz * (k0 - 1 + a.g.nbc[2]);
-
-  // z slope of the priming plane k0-1 for every row
-#pragma unroll 1
-  for (int r = 0; r < nrows; r++) {
-    const long c = crow0 + sy * ((r < nrows_l) ? r : nrows_l - 1);
-    double qa[NV], qb[NV], qc[NV], s[NV];
-    load_rot<NV, MHD>(a.S, nc, 2, c - sz, qa);
-    load_rot<NV, MHD>(a.S, nc, 2, c, qb);
-    load_rot<NV, MHD>(a.S, nc, 2, c + sz, qc);
-    slope3<NV>(qa, qb, qc, dx, oa2, s);
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      ZS(r, v) = s[v];
-      ZS(r, NV + v) = 0.0;
-    }
-  }
-
-#pragma unroll 1
-  for (int k = k0 - 1; k < k1; k++) {
-    const bool prime = (k == k0 - 1);
-    // carried from row to row inside this plane (y sweep frame)
-    double Fy[NV], ysn[NV];
-#pragma unroll
-    for (int v = 0; v < NV; v++) Fy[v] = ysn[v] = 0.0;
-
-#pragma unroll 1
-    for (int r = 0; r < nrows; r++) {
-      const bool row_ok = (r < nrows_l);
-      const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
-      // Load order matters: a wavefront's loads return in order and only one wavefront runs per SIMD,
-      // so a wait for any load also waits for every older one.  First what the x task needs at once
-      // (L1/L2 hits: this row was a y neighbour of the previous one), THEN the loads that go to HBM and
-      // are not needed for a whole Riemann solve: the start-of-step state (used after the four tasks)
-      // and the farthest y row / z plane of the stencil (used by the y and z tasks) -- their latency
-      // is covered by the x and y flux computations.
-      double q0[NV], xqm[NV], xqp[NV];
-#pragma unroll
-      for (int v = 0; v < NV; v++) q0[v] = a.S[v * nc + c];
-      if (!prime) {
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-          xqm[v] = a.S[v * nc + c - 1];
-          xqp[v] = a.S[v * nc + c + 1];
-        }
-      }
-      // HLLD -> HLL switch flags of this cell and its three upper neighbours: the x task needs two of
-      // them at once, so they are requested BEFORE the HBM-bound prefetches below (in-order return)
-      uint8_t hf0 = 0, hfx = 0, hfy = 0, hfz = 0, hfm = 0;
-      if constexpr (MHD && SOLVER == FLUX_RS_HLLD && PLAIN) {
-        hf0 = a.hllflag[c];
-        if (!prime) {
-          hfx = a.hllflag[c + 1];
-          hfy = a.hllflag[c + sy];
-          if (r == 0) hfm = a.hllflag[c - sy];   // lower y face of the group's first row
-        }
-        hfz = a.hllflag[c + sz];
-      }
-      double dU[NV];
-#pragma unroll
-      for (int v = 0; v < NV; v++) dU[v] = 0.0;
-      double P0[NV], yfar[NV], zfar[NV], ynear[NV];
-      // second-order plain instances also request the +1 y row here (register headroom permitting)
-      constexpr bool YNEAR_PRE = (OAMODE == 2 && PLAIN && NTR == 0);
-      uint8_t fl = 0;
-      const long far = oa2 ? 2 : 1;
-      // LATE_P0 (second-order plain instances): the registers of P0 first carry the +1 z plane, requested
-      // here and consumed when the z task builds its states; the start-of-step state is then requested
-      // into the same registers just before the z solve and used after it.  Both are one solve ahead of
-      // their use, for the price of one array.
-      constexpr bool LATE_P0 = (OAMODE == 2 && PLAIN && NTR == 0);   // (with tracers the extra live range spills)
-      if (LATE_P0) load_rot<NV, MHD>(a.S, nc, 2, c + sz, P0);
-      if (!prime) {
-        if (!LATE_P0) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
-          fl = a.flags[c];
-        }
-        load_rot<NV, MHD>(a.S, nc, 1, c + far * sy, yfar);
-        if (YNEAR_PRE) load_rot<NV, MHD>(a.S, nc, 1, c + sy, ynear);
-      }
-      load_rot<NV, MHD>(a.S, nc, 2, c + far * sz, zfar);
-      if (!prime && r == 0) {
-        // first row of the group: the two rows below it (the lower y task) land in the registers of the
-        // y carry, which holds nothing until that task has run
-        load_rot<NV, MHD>(a.S, nc, 1, c - sy, Fy);
-        if (oa2) load_rot<NV, MHD>(a.S, nc, 1, c - 2 * sy, ysn);
-      }
-      // small values the y and z tasks would otherwise fetch right before their solve (a dependent
-      // L2 round trip each): B_n / psi of the lower neighbours and the HLLD -> HLL switch flags
-      double ybnm = 0.0, ysim = 0.0, zbnm = 0.0, zsim = 0.0;
-      unsigned hf = 0;   // bit 0: this cell, 1: +x, 2: +y, 3: +z  (non-plain instances)
-      if constexpr (MHD) {
-        zbnm = a.S[(long)rotvar<MHD>(2, qBN) * nc + c - sz];
-        if constexpr (EQ == EQGLM) zsim = a.S[(long)qSI * nc + c - sz];
-        if (!prime) {
-          ybnm = a.S[(long)rotvar<MHD>(1, qBN) * nc + c - sy];
-          if constexpr (EQ == EQGLM) ysim = a.S[(long)qSI * nc + c - sy];
-        }
-        if constexpr (SOLVER == FLUX_RS_HLLD && !PLAIN) {
-          // (the instances with H-correction / microphysics keep the flags here, packed, after the
-          // prefetches: with the early placement the fast GLM + H-correction instances came out wrong --
-          // one more entry for the Makefile's list)
-          hf = (unsigned)a.hllflag[c] | ((unsigned)a.hllflag[c + sz] << 3);
-          if (!prime) hf |= ((unsigned)a.hllflag[c + 1] << 1) | ((unsigned)a.hllflag[c + sy] << 2);
-        }
-      }
-
-      if (!PLAIN && !prime && a.cooling != 0) {
-        if (fl & 4) {
-          // calc_noRT_microphysics_dU (time_integrator.cpp:438-489)
-          double pn[NV], ui[NV], uf[NV];
-#pragma unroll
-          for (int v = 0; v < NV; v++) pn[v] = P0[v];
-          pn[qPG] = Cooling::time_update(a.cool, P0[qRO], P0[qPG], dt, g, err);
-          E::PtoU(P0, ui, g);
-          E::PtoU(pn, uf, g);
-#pragma unroll
-          for (int v = 0; v < NV; v++) dU[v] += uf[v] - ui[v];
-        }
-      }
-
-      double ys0[NV];  // y slope of this row (kept between the two y tasks)
-      double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;
-
-#pragma unroll 1
-      for (int t = prime ? 3 : 0; t < 4; t++) {
-        if (t == 1 && r > 0) continue;  // lower y face: flux carried from the previous row
-        double eL[NV], eR[NV], f[NV], pstar[NV];
-        long cl, st;
-        int ax;
-        if (t == 0) {
-          ax = 0;
-          st = 1;
-          cl = c;
-          const double *qm = xqm, *qp = xqp;
-          double sx[NV];
-          slope3<NV>(qm, q0, qp, dx, oa2, sx);
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            double em;
-            if (oa2) {
-              eL[v] = q0[v] + sx[v] * dx * 0.5;
-              em = q0[v] - sx[v] * dx * 0.5;
-            }
-            else {
-              eL[v] = q0[v];
-              em = q0[v];
-            }
-            eR[v] = __shfl_down(em, 1, 64);
-          }
-          if constexpr (MHD) {
-            if (OAMODE == 1) {
-              // first order: the x neighbours are only needed for B_n and psi, and those are the
-              // neighbouring lanes' own cell values (the end lanes are halo lanes, their result is unused)
-              bnm = __shfl_up(q0[qBN], 1, 64);
-              bnp = __shfl_down(q0[qBN], 1, 64);
-              if constexpr (EQ == EQGLM) {
-                sim = __shfl_up(q0[qSI], 1, 64);
-                sip = __shfl_down(q0[qSI], 1, 64);
-              }
-            }
-            else {
-              bnm = qm[qBN];
-              bnp = qp[qBN];
-              if constexpr (EQ == EQGLM) {
-                sim = qm[qSI];
-                sip = qp[qSI];
-              }
-            }
-          }
-        }
-        else if (t == 1) {
-          // first row of the group: lower y face (c-sy | c); slopes of rows j-1, j (j+1 follows in t==2)
-          ax = 1;
-          st = sy;
-          cl = c - sy;
-          double qm2[NV], qm1[NV], qp1[NV], yq0[NV], sm1[NV];
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            qm1[v] = Fy[v];                   // requested at the row start
-            qm2[v] = oa2 ? ysn[v] : 0.0;
-          }
-          if (YNEAR_PRE) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) qp1[v] = ynear[v];
-          }
-          else load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
-          to_sweep<NV, MHD>(1, q0, yq0);
-          slope3<NV>(qm2, qm1, yq0, dx, oa2, sm1);
-          slope3<NV>(qm1, yq0, qp1, dx, oa2, ys0);
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            if (oa2) {
-              eL[v] = qm1[v] + sm1[v] * dx * 0.5;
-              eR[v] = yq0[v] - ys0[v] * dx * 0.5;
-            }
-            else {
-              eL[v] = qm1[v];
-              eR[v] = yq0[v];
-            }
-          }
-        }
-        else if (t == 2) {
-          // upper y face (c | c+sy): slope of the next row is new, this row's slope is ys0 / carried
-          ax = 1;
-          st = sy;
-          cl = c;
-          double yq0[NV], qp1[NV], qp2[NV], sp[NV];
-          to_sweep<NV, MHD>(1, q0, yq0);
-          if (oa2) {
-            if (YNEAR_PRE) {
-#pragma unroll
-              for (int v = 0; v < NV; v++) qp1[v] = ynear[v];
-            }
-            else load_rot<NV, MHD>(a.S, nc, 1, c + sy, qp1);
-#pragma unroll
-            for (int v = 0; v < NV; v++) qp2[v] = yfar[v];
-          }
-          else {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-              qp1[v] = yfar[v];
-              qp2[v] = 0.0;
-            }
-          }
-          if (r > 0) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) ys0[v] = ysn[v];
-          }
-          slope3<NV>(yq0, qp1, qp2, dx, oa2, sp);
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            if (oa2) {
-              eL[v] = yq0[v] + ys0[v] * dx * 0.5;
-              eR[v] = qp1[v] - sp[v] * dx * 0.5;
-            }
-            else {
-              eL[v] = yq0[v];
-              eR[v] = qp1[v];
-            }
-            ysn[v] = sp[v];
-          }
-          if constexpr (MHD) {
-            bnp = qp1[qBN];
-            bnm = ybnm;
-            if constexpr (EQ == EQGLM) {
-              sip = qp1[qSI];
-              sim = ysim;
-            }
-          }
-        }
-        else {
-          // upper z face (c | c+sz)
-          ax = 2;
-          st = sz;
-          cl = c;
-          double zq0[NV], qp1[NV], qp2[NV], sn[NV];
-          to_sweep<NV, MHD>(2, q0, zq0);
-          if (oa2) {
-            if (LATE_P0) {
-#pragma unroll
-              for (int v = 0; v < NV; v++) qp1[v] = P0[v];   // the +1 plane requested at the row start
-            }
-            else load_rot<NV, MHD>(a.S, nc, 2, c + sz, qp1);
-#pragma unroll
-            for (int v = 0; v < NV; v++) qp2[v] = zfar[v];
-          }
-          else {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-              qp1[v] = zfar[v];
-              qp2[v] = 0.0;
-            }
-          }
-          slope3<NV>(zq0, qp1, qp2, dx, oa2, sn);
-#pragma unroll
-          for (int v = 0; v < NV; v++) {
-            const double sc = ZS(r, v);
-            if (oa2) {
-              eL[v] = zq0[v] + sc * dx * 0.5;
-              eR[v] = qp1[v] - sn[v] * dx * 0.5;
-            }
-            else {
-              eL[v] = zq0[v];
-              eR[v] = qp1[v];
-            }
-            ZS(r, v) = sn[v];
-          }
-          if constexpr (MHD) {
-            bnp = qp1[qBN];
-            bnm = zbnm;
-            if constexpr (EQ == EQGLM) {
-              sip = qp1[qSI];
-              sim = zsim;
-            }
-          }
-        }
-
-        double hc_eta = 0.0;
-        if (hcorr) hc_eta = select_hcorr_eta(a, ax, cl, st);
-        bool use_hll = false;
-        if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-          if constexpr (PLAIN) {
-            if (t == 0) use_hll = (hf0 | hfx) != 0;
-            else if (t == 1) use_hll = (hfm | hf0) != 0;
-            else if (t == 2) use_hll = (hf0 | hfy) != 0;
-            else use_hll = (hf0 | hfz) != 0;
-          }
-          else {
-            if (t == 0) use_hll = (hf & 3u) != 0;
-            else if (t == 1) use_hll = (a.hllflag[cl] | (hf & 1u)) != 0;
-            else if (t == 2) use_hll = (hf & 5u) != 0;
-            else use_hll = (hf & 9u) != 0;
-          }
-        }
-        if (LATE_P0 && t == 3 && !prime) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) P0[v] = a.Pc[v * nc + c];
-          fl = a.flags[c];
-        }
-        FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
-
-        if (t == 0) {
-          double Fm[NV];
-#pragma unroll
-          for (int v = 0; v < NV; v++) Fm[v] = __shfl_up(f[v], 1, 64);
-          apply_axis<EQ, NV>(dU, q0, bnm, sim, bnp, sip, Fm, f, dt, dx);
-        }
-        else if (t == 1) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) Fy[v] = f[v];
-        }
-        else if (t == 2) {
-          double d[NV], yq0[NV];
-          to_sweep<NV, MHD>(1, q0, yq0);
-          to_sweep<NV, MHD>(1, dU, d);
-          apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
-          from_sweep<NV, MHD>(1, d, dU);
-#pragma unroll
-          for (int v = 0; v < NV; v++) Fy[v] = f[v];  // lower-face flux of the next row
-        }
-        else {
-          if (!prime) {
-            double d[NV], zq0[NV], Fzl[NV];
-            to_sweep<NV, MHD>(2, q0, zq0);
-            to_sweep<NV, MHD>(2, dU, d);
-#pragma unroll
-            for (int v = 0; v < NV; v++) Fzl[v] = ZS(r, NV + v);
-            apply_axis<EQ, NV>(d, zq0, bnm, sim, bnp, sip, Fzl, f, dt, dx);
-            from_sweep<NV, MHD>(2, d, dU);
-          }
-#pragma unroll
-          for (int v = 0; v < NV; v++) ZS(r, NV + v) = f[v];
-        }
-      }
-
-      if (!prime && writer && row_ok) {
-        double Pf[NV];
-        if (!(fl & 4) || !(fl & 16)) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) a.out[v * nc + c] = Pf[v] = P0[v];
-        }
-        else cell_update_store<EQ, NTR>(a, c, P0, dU, err, Pf, PLAIN);
-        if (a.dtres) {
-          // calc_dynamics_dt / calc_microphysics_dt (calc_timestep.cpp:271-507) of the state just
-          // written: after a full step it is the state the next step's dt is computed from
-          if ((fl & 8) && !(fl & 2)) {
-            const double t = cell_dt<EQ>(Pf, a.g.ndim, g, dx, a.cfl);
-            if (!(t > 0.0)) err |= ERR_BAD_DT;
-            tdyn = (t < tdyn) ? t : tdyn;
-          }
-          if (a.dt_mp && !(fl & 2) && (fl & 16)) {
-            const double t = Cooling::timescale(a.cool, Pf[qRO], Pf[qPG], g);
-            tmp = (t < tmp) ? t : tmp;
-          }
-        }
-      }
-    }
-  }
-#undef ZS
-  if (a.dtres) {
-    tdyn = wave_min64(tdyn);
-    tmp = wave_min64(tmp);
-    if (lane == 0) {
-      atomicMin(&a.dtres[0], (unsigned long long)__double_as_longlong(tdyn));
-      atomicMin(&a.dtres[1], (unsigned long long)__double_as_longlong(tmp));
-    }
-  }
-  if (err) atomicOr(a.errword, err);
-}
-
-template <int EQ, int NTR, int SOLVER>
-static int stage_rows_go(const StageArgs &a0, hipStream_t s)
-{
-  constexpr int NV = Eqn<EQ, NTR>::NV;
-  // rows per wavefront limited by the 160 KiB of LDS a 4-wave workgroup may hold
-  StageArgs a = a0;
-  const int rmax = (int)((160 * 1024) / (sizeof(double) * 4 * (2 * NV) * 64));
-  if (a.rows > rmax) a.rows = rmax;
-  if (a.rows < 1) a.rows = 1;
-  const int R = a.rows;
-  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
-  const long ntiles = (long)rows_tiling(a).per_chunk * nzc;
-  const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
-  const size_t shmem = sizeof(double) * 4 * R * (2 * NV) * 64;
-  // compile-time spatial order for the MHD HLLD, Euler Roe-CV and Euler FVS instances (the production
-  // configurations M1, M2, M3; both specialised
-  // kernels run in every OA2/OA2 step, so tests/test_gpu_parity.py::test_every_mhd_instantiation_3d covers
-  // them); one more specialised instance of another solver aborted on the device in testing, like the
-  // other per-instance miscompiles listed in the Makefile, so the rest keep the run-time form
-  constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)
-                              || ((SOLVER == FLUX_RSroe || SOLVER == FLUX_FVS) && EQ == EQEUL);
-  if constexpr (specialise) {
-    const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
-                        && a.fc.artvisc != AV_HCORR_FKJ98);
-    if (plain) {
-      if (a.space_ooa == 2)
-        hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 2, true>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-      else
-        hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 1, true>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-    }
-    else if (a.space_ooa == 2)
-      hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 2, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-    else
-      hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 1, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-  }
-  else
-    hipLaunchKernelGGL((k_stage_rows<EQ, NTR, SOLVER, 0, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-  return (int)hipGetLastError();
 }
 
 #endif
