@@ -1,0 +1,183 @@
+// pion_gpu_bridge.cpp -- see pion_gpu_bridge.h
+#include "pion_gpu_bridge.h"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+static int gpu_bc_type(int itype)
+{
+  switch (itype) {   // boundaries/boundaries.h:31-72 -> include/pion_gpu.h
+    case PERIODIC: return PION_BC_PERIODIC;
+    case OUTFLOW: return PION_BC_OUTFLOW;
+    case INFLOW: return PION_BC_INFLOW;
+    case REFLECTING: return PION_BC_REFLECTING;
+    case FIXED: return PION_BC_FIXED;
+    case ONEWAY_OUT: return PION_BC_ONEWAY_OUT;
+    case DMACH: return PION_BC_DMACH;
+    case AXISYMMETRIC: return PION_BC_AXISYMMETRIC;
+    case JETREFLECT: return PION_BC_JETREFLECT;
+    default: return -1;
+  }
+}
+
+pion_gpu_bridge::pion_gpu_bridge(class SimParams &par, class GridBaseClass *grid, int device, int strict_fp)
+    : par_(par), grid_(grid), h_(nullptr), ncell_(0)
+{
+  memset(&cfg_, 0, sizeof cfg_);
+  cfg_.ndim = par.ndim;
+  cfg_.nvar = par.nvar;
+  cfg_.ntracer = par.ntracer;
+  cfg_.eqntype = par.eqntype;          // EQEUL 1, EQMHD 2, EQGLM 3 (constants.h:163-170), same numbering
+  cfg_.solver = par.solverType;        // FLUX_* (constants.h:238-246), same numbering
+  cfg_.artvisc = par.artviscosity;
+  cfg_.sp_ooa = par.spOOA;
+  cfg_.tm_ooa = par.tmOOA;
+  cfg_.coord_sys = (par.coord_sys == COORD_CYL) ? 2 : ((par.coord_sys == COORD_SPH) ? 3 : 1);
+  cfg_.nbc = par.Nbc;
+  for (int a = 0; a < 3; a++) {
+    cfg_.ng[a] = (a < par.ndim) ? par.NG[a] : 1;
+    cfg_.xmin[a] = par.Xmin[a];
+  }
+  cfg_.dx = par.dx;
+  cfg_.gamma = par.gamma;
+  cfg_.cfl = par.CFL;
+  cfg_.etav = par.etav;
+  cfg_.min_temp = par.EP.MinTemperature;
+  cfg_.max_temp = par.EP.MaxTemperature;
+  for (int v = 0; v < par.nvar && v < PION_MAX_NVAR; v++) cfg_.refvec[v] = par.RefVec[v];
+  // external boundaries in list order XN, XP, YN, YP, ZN, ZP (uniform_grid.cpp:1009-1216); DMR2 is the internal one
+  for (size_t i = 0; i < grid->BC_bd.size(); i++) {
+    const struct boundary_data *b = grid->BC_bd[i];
+    if (b->itype == DMACH2) {
+      cfg_.bc_dmach2 = 1;
+      continue;
+    }
+    const int d = static_cast<int>(b->dir);
+    if (d < 0 || d >= 2 * par.ndim) continue;
+    const int t = gpu_bc_type(b->itype);
+    if (t < 0) throw std::runtime_error("pion_gpu_bridge: boundary type not handled on the device");
+    cfg_.bc_type[d] = t;
+  }
+  cfg_.cooling = par.EP.cooling;
+  cfg_.mp_timestep_limit = par.EP.MP_timestep_limit;
+  cfg_.strict_fp = strict_fp;
+  const int rc = pion_gpu_create(&cfg_, device, &h_);
+  if (rc != 0) throw std::runtime_error("pion_gpu_create failed: " + last_error());
+  ncell_ = 1;
+  for (int a = 0; a < par.ndim; a++) ncell_ *= par.NG[a] + 2 * par.Nbc;
+  soa_.resize((size_t)cfg_.nvar * ncell_);
+}
+
+pion_gpu_bridge::~pion_gpu_bridge()
+{
+  if (h_) pion_gpu_destroy(h_);
+}
+
+std::string pion_gpu_bridge::last_error() const
+{
+  char buf[512] = {0};
+  if (h_) pion_gpu_last_error(h_, buf, sizeof buf);
+  return buf;
+}
+
+int pion_gpu_bridge::gather_and_upload()
+{
+  long i = 0;
+  class cell *c = grid_->FirstPt_All();
+  do {
+    if (i >= ncell_) return PION_GPU_EINVAL;
+    for (int v = 0; v < cfg_.nvar; v++) soa_[(size_t)v * ncell_ + i] = c->P[v];
+    i++;
+  } while ((c = grid_->NextPt_All(c)) != 0);
+  if (i != ncell_) return PION_GPU_EINVAL;
+  int err = pion_gpu_upload(h_, soa_.data());
+  err += pion_gpu_update_bcs(h_, par_.simtime, cfg_.tm_ooa, cfg_.tm_ooa, 1);
+  return err;
+}
+
+int pion_gpu_bridge::download_and_scatter()
+{
+  int err = pion_gpu_download(h_, 0, soa_.data());
+  if (err) return err;
+  long i = 0;
+  class cell *c = grid_->FirstPt_All();
+  do {
+    for (int v = 0; v < cfg_.nvar; v++) {
+      c->P[v] = c->Ph[v] = soa_[(size_t)v * ncell_ + i];
+      c->dU[v] = 0.0;
+    }
+    i++;
+  } while ((c = grid_->NextPt_All(c)) != 0);
+  return 0;
+}
+
+int pion_gpu_bridge::calculate_timestep()
+{
+  double t_dyn = 0.0, t_mp = 0.0;
+  int err = pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
+  if (err) return err;
+  par_.dt = std::min(t_dyn, t_mp);
+  // Set_GLM_Speeds(td, dx, 0.25/dx) with the dynamical step (calc_timestep.cpp:119-131)
+  if (cfg_.eqntype == PION_EQGLM) err += pion_gpu_set_glm_speeds(h_, t_dyn, par_.dx, 0.25 / par_.dx);
+  // timestep_checking_and_limiting (calc_timestep.cpp:219-262)
+  if (par_.dt < par_.min_timestep) rep.error("Timestep too short! dt", par_.dt);
+  par_.dt = std::min(par_.dt, 1.3 * par_.last_dt);
+  par_.dt = std::min(par_.dt, par_.finishtime - par_.simtime);
+  if (par_.dt <= 0.0) rep.error("Negative timestep!", par_.dt);
+  return err;
+}
+
+int pion_gpu_bridge::advance_time()
+{
+  // time_integrator::advance_time (time_integrator.cpp:72-142): the stages and boundary updates of the
+  // (1,1) and (2,2) schemes run on the device
+  const int err = pion_gpu_advance_time(h_, par_.dt, par_.simtime);
+  if (err) return err;
+  par_.simtime += par_.dt;
+  par_.last_dt = par_.dt;
+  par_.timestep++;
+  return 0;
+}
+
+int pion_gpu_bridge::Time_Int(int nsteps)
+{
+  int n = 0;
+  while (par_.simtime < par_.finishtime && (nsteps < 0 || n < nsteps)) {
+    int err = calculate_timestep();
+    err += advance_time();
+    if (err) rep.error(last_error(), err);
+    n++;
+  }
+  return n;
+}
+
+// ---- C entry for the test: drive the grid of an oracle/ref_harness.cpp RefSim ---------------------------------
+extern "C" {
+void *ref_simparams(void *h);   // oracle/ref_harness.cpp
+void *ref_grid(void *h);
+int ref_bridge_time_int(void *refsim, int device, int strict_fp, int nsteps, double *simtime, double *last_dt)
+{
+  class SimParams &par = *static_cast<class SimParams *>(ref_simparams(refsim));
+  class GridBaseClass *grid = static_cast<class GridBaseClass *>(ref_grid(refsim));
+  // what sim_init / the parameter file would have set (the harness leaves them at their defaults)
+  if (par.finishtime <= par.simtime) par.finishtime = 1.0e300;
+  if (par.timestep == 0) par.last_dt = 1.0e100;
+  par.min_timestep = 0.0;
+  try {
+    pion_gpu_bridge b(par, grid, device, strict_fp);
+    int err = b.gather_and_upload();
+    if (err) return -100 + err;
+    const int n = b.Time_Int(nsteps);
+    err = b.download_and_scatter();
+    if (err) return -200 + err;
+    *simtime = par.simtime;
+    *last_dt = par.last_dt;
+    return n;
+  }
+  catch (const std::exception &e) {
+    fprintf(stderr, "ref_bridge_time_int: %s\n", e.what());
+    return -1;
+  }
+}
+}
