@@ -141,7 +141,7 @@ def cpu_baseline(n, eqn, budget_s=10.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     C = 1
-    while C * 2 <= min(cores, 64) and n % (C * 2) == 0 and n // (C * 2) >= 4:
+    while C * 2 <= min(cores, 16) and n % (C * 2) == 0 and n // (C * 2) >= 4:   # (a one-GPU box's CPU share is 16 cores)
         C *= 2
     rate = lambda r: r["cells"] * r["steps"] / r["seconds"] / 1e6
     res_all = _run_cpu_workers(["%s,m1,%s,%d,%d,%d,%g" % (kind, eqn, n, n, n // C, budget_s)] * C)

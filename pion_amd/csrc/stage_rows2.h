@@ -97,6 +97,9 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #ifndef PION_ROWS2_PF
 #define PION_ROWS2_PF 1
 #endif
+#ifndef PION_ROWS2_YWG
+#define PION_ROWS2_YWG 1
+#endif
 
 template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN, bool ZSL>
 __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
@@ -124,8 +127,17 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
   int ix, jg, jg_first;   // jg: this LANE's row group; jg_first: the wavefront's first (uniform)
   bool writer;
   if (tt < tl.nfull) {
+#if PION_ROWS2_YWG
+    // the four wavefronts of a workgroup take four y-adjacent row groups of the same x tile: the y halo rows
+    // of one are the own rows of the next, read at about the same time on the same CU / L2
+    const int per4 = 4 * tl.ntx_full, g4 = tt / per4, r4 = tt - g4 * per4;
+    const int m = (nyg - 4 * g4 < 4) ? nyg - 4 * g4 : 4;
+    const int tx = r4 / m;
+    jg = jg_first = 4 * g4 + r4 % m;
+#else
     const int tx = tt % tl.ntx_full;
     jg = jg_first = tt / tl.ntx_full;
+#endif
     ix = tx * PION_MARCH_XT - 1 + lane;
     writer = (lane >= 1 && lane <= PION_MARCH_XT && ix < a.g.ng[0]);
   }
