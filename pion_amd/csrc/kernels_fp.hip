@@ -736,23 +736,42 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
   if (i[0] >= a.g.nga[0] || i[1] >= a.g.nga[1]) return;
   const long c = (long)i[0] + a.g.sy * i[1] + a.g.sz * i[2];
   const double dx = a.g.dx;
+  // The switch is (div v < 0 && grad > 5): the pressure term decides for almost every cell (grad > 5 only
+  // in strong shocks), so it is evaluated first and the three velocity arrays are read only where it can
+  // matter -- the same flags from a quarter of the memory traffic.
+  // ... and the pressure term itself is screened without its divisions: if |dp| <= 1.6 min(p-, p+) on every
+  // axis the sum of the (at most three) quotients is <= 4.8 (1 + a few ulp) < 5 and the flag is 0 whatever
+  // the exact value; only the other cells (and the debug outputs) pay for the divisions.
   double divv = 0.0, gradp = 0.0;
+  double pp3[3], pn3[3];
+  bool steep = (a.gradp != nullptr);
   for (int v = 0; v < a.g.ndim; v++) {
     const long st = (v == 0) ? 1 : ((v == 1) ? a.g.sy : a.g.sz);
-    // Divergence (VectorOps.cpp:377-439): missing neighbour -> this cell, one-sided dx
     const long n = (i[v] > 0) ? c - st : c;
     const long p = (i[v] < a.g.nga[v] - 1) ? c + st : c;
-    const double ddx = (n == c || p == c) ? dx : 2.0 * dx;
-    if (a.g.cyl == 1 && v == 1) {
-      // VectorOps_Cyl::Divergence (VectorOps.cpp:891-972): d(R V_R)/(R dR) between the neighbours' centres of mass
-      const double rn = cyl_Rcom(cyl_R(a.g, (n == c) ? i[1] : i[1] - 1), dx);
-      const double rp = cyl_Rcom(cyl_R(a.g, (p == c) ? i[1] : i[1] + 1), dx);
-      divv += 2.0 * (rp * a.S[(2 + v) * nc + p] - rn * a.S[(2 + v) * nc + n]) / (rp * rp - rn * rn);
-    }
-    else divv += (a.S[(2 + v) * nc + p] - a.S[(2 + v) * nc + n]) / ddx;
+    pp3[v] = a.S[1 * nc + p];
+    pn3[v] = a.S[1 * nc + n];
+    if (!(fabs(pp3[v] - pn3[v]) <= 1.6 * fmin(pp3[v], pn3[v]))) steep = true;   // (NaN counts as steep)
+  }
+  if (steep) {
     // GradZone (VectorOps.cpp:322-368) on the pressure
-    const double pp = a.S[1 * nc + p], pn = a.S[1 * nc + n];
-    gradp += fabs(pp - pn) / fmin(pp, pn);
+    for (int v = 0; v < a.g.ndim; v++) gradp += fabs(pp3[v] - pn3[v]) / fmin(pp3[v], pn3[v]);
+  }
+  if (gradp > 5. || a.divv) {
+    for (int v = 0; v < a.g.ndim; v++) {
+      const long st = (v == 0) ? 1 : ((v == 1) ? a.g.sy : a.g.sz);
+      // Divergence (VectorOps.cpp:377-439): missing neighbour -> this cell, one-sided dx
+      const long n = (i[v] > 0) ? c - st : c;
+      const long p = (i[v] < a.g.nga[v] - 1) ? c + st : c;
+      const double ddx = (n == c || p == c) ? dx : 2.0 * dx;
+      if (a.g.cyl == 1 && v == 1) {
+        // VectorOps_Cyl::Divergence (VectorOps.cpp:891-972): d(R V_R)/(R dR) between the neighbours' centres of mass
+        const double rn = cyl_Rcom(cyl_R(a.g, (n == c) ? i[1] : i[1] - 1), dx);
+        const double rp = cyl_Rcom(cyl_R(a.g, (p == c) ? i[1] : i[1] + 1), dx);
+        divv += 2.0 * (rp * a.S[(2 + v) * nc + p] - rn * a.S[(2 + v) * nc + n]) / (rp * rp - rn * rn);
+      }
+      else divv += (a.S[(2 + v) * nc + p] - a.S[(2 + v) * nc + n]) / ddx;
+    }
   }
   if (a.divv) a.divv[c] = divv;
   if (a.gradp) a.gradp[c] = gradp;
