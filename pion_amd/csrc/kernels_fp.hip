@@ -779,6 +779,67 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
   a.hllflag[c] = (divv < 0. && gradp > 5.) ? 1 : 0;
 }
 
+// The same flags, one thread per (x,y) column of a chunk of PION_PREPASS_ZC planes (3-D Cartesian grids, whole
+// plane ranges): the pressure of planes k-1, k, k+1 is carried in registers, so each plane of p is read once
+// (+ 2 halo planes per chunk) instead of three times from beyond L2, and -- as in k_prepass_hlld -- the pressure
+// term is screened without divisions and the velocities are read only in steep cells.
+#define PION_PREPASS_ZC 16
+__global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
+{
+  const long nc = a.g.ncell;
+  const unsigned gx = (a.g.nga[0] + 63) / 64, gy = (a.g.nga[1] + 3) / 4;
+  const long plane = (long)a.g.nga[0] * a.g.nga[1];
+  const int kz0 = (int)(a.c0 / plane), kz1 = (int)(a.c1 / plane);
+  const unsigned nch = (unsigned)((kz1 - kz0 + PION_PREPASS_ZC - 1) / PION_PREPASS_ZC);
+  const unsigned ntile = gx * gy * nch;
+  const unsigned t = (unsigned)xcd_tile(blockIdx.x, ntile);
+  if (t >= ntile) return;
+  const int ix = (int)((t % gx) * 64 + (threadIdx.x & 63));
+  const int iy = (int)(((t / gx) % gy) * 4 + (threadIdx.x >> 6));
+  const int k0 = kz0 + (int)(t / (gx * gy)) * PION_PREPASS_ZC;
+  const int k1 = (k0 + PION_PREPASS_ZC < kz1) ? k0 + PION_PREPASS_ZC : kz1;
+  if (ix >= a.g.nga[0] || iy >= a.g.nga[1]) return;
+  const long sy = a.g.sy, sz = a.g.sz;
+  const double dx = a.g.dx;
+  const double *P = a.S + 1 * nc;
+  long c = (long)ix + sy * iy + sz * k0;
+  const bool xl = ix > 0, xh = ix < a.g.nga[0] - 1, yl = iy > 0, yh = iy < a.g.nga[1] - 1;
+  double p0 = P[c], pm = (k0 > 0) ? P[c - sz] : p0;
+  for (int k = k0; k < k1; k++, c += sz) {
+    const bool zl = k > 0, zh = k < a.g.nga[2] - 1;
+    const double pz = zh ? P[c + sz] : p0;
+    double pn3[3], pp3[3];
+    pn3[0] = xl ? P[c - 1] : p0;
+    pp3[0] = xh ? P[c + 1] : p0;
+    pn3[1] = yl ? P[c - sy] : p0;
+    pp3[1] = yh ? P[c + sy] : p0;
+    pn3[2] = zl ? pm : p0;
+    pp3[2] = pz;
+    bool steep = false;
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+      if (!(fabs(pp3[v] - pn3[v]) <= 1.6 * fmin(pp3[v], pn3[v]))) steep = true;   // (NaN counts as steep)
+    uint8_t flag = 0;
+    if (steep) {
+      double gradp = 0.0, divv = 0.0;
+      for (int v = 0; v < 3; v++) gradp += fabs(pp3[v] - pn3[v]) / fmin(pp3[v], pn3[v]);   // GradZone
+      if (gradp > 5.) {
+        const bool lo[3] = {xl, yl, zl}, hi[3] = {xh, yh, zh};
+        for (int v = 0; v < 3; v++) {
+          const long st = (v == 0) ? 1 : ((v == 1) ? sy : sz);
+          const long n = lo[v] ? c - st : c, p = hi[v] ? c + st : c;
+          const double ddx = (n == c || p == c) ? dx : 2.0 * dx;
+          divv += (a.S[(2 + v) * nc + p] - a.S[(2 + v) * nc + n]) / ddx;   // Divergence (VectorOps.cpp:377-439)
+        }
+        flag = (divv < 0.) ? 1 : 0;
+      }
+    }
+    a.hllflag[c] = flag;
+    pm = p0;
+    p0 = pz;
+  }
+}
+
 // eta of interface (c | c+st) along each axis, stored at c (calc_Hcorrection; the last cell of a
 // column gets no value and keeps 0; first/last cells of a column have zero slope)
 template <int NVMAX>
@@ -863,7 +924,12 @@ int launch_prepass(const PrepassArgs &a, hipStream_t s)
     const long plane = (long)a.g.nga[0] * a.g.nga[1];
     const unsigned npl = (unsigned)((a.c1 - a.c0) / plane) + ((a.c3 > a.c2) ? (unsigned)((a.c3 - a.c2) / plane) : 0u);
     const unsigned ntile = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * npl;
-    hipLaunchKernelGGL(k_prepass_hlld, dim3(((ntile + 7) / 8) * 8), dim3(256), 0, s, a);
+    if (a.g.ndim == 3 && a.g.cyl == 0 && !a.divv && !a.gradp && a.c3 <= a.c2 && npl >= PION_PREPASS_ZC) {
+      const unsigned nch = (npl + PION_PREPASS_ZC - 1) / PION_PREPASS_ZC;
+      const unsigned nt = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * nch;
+      hipLaunchKernelGGL(k_prepass_hlld_march, dim3(((nt + 7) / 8) * 8), dim3(256), 0, s, a);
+    }
+    else hipLaunchKernelGGL(k_prepass_hlld, dim3(((ntile + 7) / 8) * 8), dim3(256), 0, s, a);
   }
   if (a.eta) hipLaunchKernelGGL((k_prepass_hcorr<8>), dim3(nb), dim3(256), 0, s, a);
   return (int)hipGetLastError();

@@ -1116,11 +1116,8 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows)
                            : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows);
   if (a.zchunk <= 0) {
-    // Planes per wavefront.  Every wavefront takes about (zchunk + 1 priming plane) plane visits, a CU holds
-    // `slots` wavefronts at a time (k_stage_rows: 4, k_stage_rows2: 8), and a launch proceeds in rounds of
-    // equal wavefronts, so its cost is ceil(wavefronts / slots) x (zchunk + 1): pick the chunk that
-    // minimises it.
-    const int nv = cfg.nvar;
+    // Planes per wavefront.  Every wavefront takes (zchunk + 1 priming plane) plane visits and a CU holds 8
+    // wavefronts at a time; pick the chunk that minimises the launch cost model below.
     int rows = a.rows;
     if (rows < 1) rows = 1;
     const int nyg = (h->g.ng[1] + rows - 1) / rows;
@@ -1129,14 +1126,18 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     const long per_chunk = (long)ntx_full * nyg + ((rem > 0) ? (nyg + spw - 1) / spw : 0);
     const long slots = 8L * (h->ncu > 0 ? h->ncu : 256);   // two workgroups of four wavefronts per CU
     const int np = kz1 - kz0;
-    long best_cost = -1;
+    // cost in plane visits: wavefronts are dispatched as slots free up, so a launch takes about
+    // (all wave-visits) / slots plus a tail of half a wavefront's length; short chunks balance better, long
+    // chunks prime less (measured at 512^3: 16 and 32 planes 27.3 ms/step, 47: 28.4, 64: 28.0, 128: 31.7)
+    double best_cost = -1.0;
     a.zchunk = 8;
     for (int zc = 8; zc <= 128; zc++) {
       const long nzc = (np + zc - 1) / zc;
-      const long rounds = (per_chunk * nzc + slots - 1) / slots;
       const int longest = (zc < np ? zc : np) + 1;
-      const long cost = rounds * longest;
-      if (best_cost < 0 || cost <= best_cost) {   // ties: the longer chunk (fewer priming planes)
+      const int last = np - (int)(nzc - 1) * zc;           // planes of the last chunk
+      if (nzc > 1 && 4 * last < 3 * zc) continue;          // a short last chunk unbalances the tail (22, 26: measured)
+      const double cost = (double)per_chunk * (double)(np + nzc) / (double)slots + 0.5 * longest;
+      if (best_cost < 0 || cost < best_cost) {
         best_cost = cost;
         a.zchunk = zc;
       }
