@@ -1136,7 +1136,8 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
       const int longest = (zc < np ? zc : np) + 1;
       const int last = np - (int)(nzc - 1) * zc;           // planes of the last chunk
       if (nzc > 1 && 4 * last < 3 * zc) continue;          // a short last chunk unbalances the tail (22, 26: measured)
-      const double cost = (double)per_chunk * (double)(np + nzc) / (double)slots + 0.5 * longest;
+      double cost = (double)per_chunk * (double)(np + nzc) / (double)slots + 0.5 * longest;
+      if (np % zc != 0) cost *= 1.005;                     // equal chunks first (512^3: 32 planes 25.5, 27 planes 25.8 ms/step)
       if (best_cost < 0 || cost < best_cost) {
         best_cost = cost;
         a.zchunk = zc;
