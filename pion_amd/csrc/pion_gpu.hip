@@ -245,6 +245,10 @@ struct Handle {
   hipStream_t stream = 0;
   hipStream_t comm_stream = 0;     // pack/unpack of the z halo (0: the compute stream)
   hipEvent_t ev_packed_src = nullptr, ev_unpacked = nullptr;
+  hipStream_t bstream = 0;         // the z-boundary strips of a split stage (two-stream mode): beside the interior part
+  hipEvent_t ev_pre = nullptr, ev_bdone = nullptr;
+  bool ev_pre_valid = false;
+  bool concurrent_strips = true;   // PION_CONCURRENT_STRIPS=0: strips after the interior part on the compute stream
   bool ev_unpacked_valid = false;
   double *dP = nullptr, *dPh = nullptr;
   bool own_state = true;
@@ -423,6 +427,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (const char *e = getenv("PION_STAGE_KERNEL"))
     h->use_march = (strcmp(e, "cell") == 0) ? 0 : 3;
   if (const char *e = getenv("PION_ZSLOPE_LDS")) h->zslope_lds = (atoi(e) != 0);
+  if (const char *e = getenv("PION_CONCURRENT_STRIPS")) h->concurrent_strips = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
   if (const char *e = getenv("PION_ROWS")) h->rows = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
@@ -607,6 +612,9 @@ void pion_gpu_destroy(void *handle)
   hipFree(h->dflags);
   hipFree(h->dhll);
   hipFree(h->ddE);
+  if (h->bstream) hipStreamDestroy(h->bstream);
+  if (h->ev_pre) hipEventDestroy(h->ev_pre);
+  if (h->ev_bdone) hipEventDestroy(h->ev_bdone);
   if (h->hdt) hipHostFree(h->hdt);
   if (h->ev_dt) hipEventDestroy(h->ev_dt);
   hipFree(h->deta);
@@ -701,6 +709,7 @@ int pion_gpu_synchronize(void *handle)
   Handle *h = use(handle);
   HCHECK(h, hipStreamSynchronize(h->stream));
   if (h->comm_stream && h->comm_stream != h->stream) HCHECK(h, hipStreamSynchronize(h->comm_stream));
+  if (h->bstream) HCHECK(h, hipStreamSynchronize(h->bstream));
   return 0;
 }
 
@@ -1018,8 +1027,9 @@ static bool stage_can_split(const Handle *h)
 
 // planes [kz0,kz1) and, if kz3 > kz2, also [kz2,kz3) (the two z-boundary strips go out as ONE launch)
 static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_step, int kz0, int kz1,
-                        bool first, bool last, int kz2 = 0, int kz3 = 0)
+                        bool first, bool last, int kz2 = 0, int kz3 = 0, hipStream_t ls = 0, bool use_ls = false)
 {
+  if (!use_ls) ls = h->stream;   // launch stream: the compute stream unless the caller runs this part beside it
   const pion_gpu_config &cfg = h->cfg;
   if (cfg.cooling != 0 && !h->have_tables) {
     h->err = "cooling tables not set";
@@ -1067,7 +1077,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
       p.c3 = (long)(nz + 1 + nb) * h->g.sz;
     }
     time_begin(h, 1);
-    rc = cfg.strict_fp ? fp_strict::launch_prepass(p, h->stream) : fp_fast::launch_prepass(p, h->stream);
+    rc = cfg.strict_fp ? fp_strict::launch_prepass(p, ls) : fp_fast::launch_prepass(p, ls);
     time_end(h, 1);
     if (rc != 0) {
       h->err = "prepass launch failed";
@@ -1148,7 +1158,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     // calc_noRT_microphysics_dU as its own launch (thread per cell, full occupancy): dE per cell
     a.dE = h->ddE;
     time_begin(h, 1);
-    rc = cfg.strict_fp ? fp_strict::launch_cooling_dE(a, h->stream) : fp_fast::launch_cooling_dE(a, h->stream);
+    rc = cfg.strict_fp ? fp_strict::launch_cooling_dE(a, ls) : fp_fast::launch_cooling_dE(a, ls);
     time_end(h, 1);
     if (rc != 0) {
       h->err = "cooling kernel launch failed";
@@ -1165,11 +1175,19 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   h->dt_cached = false;
   if (fuse_dt) {
     if (first)
-      HCHECK(h, hipMemcpyAsync(h->ddt, h->ddt_init, 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      HCHECK(h, hipMemcpyAsync(h->ddt, h->ddt_init, 2 * sizeof(double), hipMemcpyDeviceToDevice, ls));
     a.dtres = h->ddt;
   }
+  if (first && !last && h->concurrent_strips && !h->timing && h->comm_stream && h->comm_stream != h->stream) {
+    // interior part of a split stage: everything the z-boundary strips depend on besides the halo (the
+    // previous stage, its boundary update, this part's flags, the reset of the dt minima) is on the stream up
+    // to here -- the strips may run beside the interior kernel from this point on (pion_gpu_stage_part)
+    if (!h->ev_pre) HCHECK(h, hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming));
+    HCHECK(h, hipEventRecord(h->ev_pre, ls));
+    h->ev_pre_valid = true;
+  }
   time_begin(h, 0);
-  rc = cfg.strict_fp ? fp_strict::launch_stage(a, h->stream) : fp_fast::launch_stage(a, h->stream);
+  rc = cfg.strict_fp ? fp_strict::launch_stage(a, ls) : fp_fast::launch_stage(a, ls);
   time_end(h, 0);
   if (rc != 0) {
     h->err = "stage kernel launch failed (unsupported eqn/solver/tracer combination?)";
@@ -1179,7 +1197,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   if (is_full_step && a.out == h->dPh) {
     // OA1/OA1: copy the result back to P ("P = Ph", time_integrator.cpp:938-939)
     const size_t nb = sizeof(double) * (size_t)cfg.nvar * h->g.ncell;
-    HCHECK(h, hipMemcpyAsync(h->dP, h->dPh, nb, hipMemcpyDeviceToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->dP, h->dPh, nb, hipMemcpyDeviceToDevice, ls));
   }
   h->ph_valid = !is_full_step;
   h->dt_cached = fuse_dt;
@@ -1200,6 +1218,23 @@ int pion_gpu_stage_part(void *handle, double dt_stage, int space_ooa, int is_ful
     return stage_launch(h, dt_stage, space_ooa, is_full_step, nb, nz - nb, true, false);
   }
   if (part != PION_STAGE_ZBOUNDARY) return PION_GPU_EINVAL;
+  if (split && h->ev_pre_valid && h->ev_unpacked_valid) {
+    // Two-stream mode: the strips (4 of the slab's planes: a launch of ~2100 short wavefronts on 2048 slots)
+    // go to a third stream that waits for the halo and for the point of the compute stream just before the
+    // interior kernel, so that they fill the slots the interior launch leaves idle in its last round instead
+    // of running after it; the compute stream continues behind both.
+    h->ev_pre_valid = false;
+    if (!h->bstream) HCHECK(h, hipStreamCreateWithFlags(&h->bstream, hipStreamNonBlocking));
+    if (!h->ev_bdone) HCHECK(h, hipEventCreateWithFlags(&h->ev_bdone, hipEventDisableTiming));
+    HCHECK(h, hipStreamWaitEvent(h->bstream, h->ev_pre, 0));
+    HCHECK(h, hipStreamWaitEvent(h->bstream, h->ev_unpacked, 0));
+    const int rc = stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nb, false, true, nz - nb, nz, h->bstream, true);
+    if (rc) return rc;
+    HCHECK(h, hipEventRecord(h->ev_bdone, h->bstream));
+    HCHECK(h, hipStreamWaitEvent(h->stream, h->ev_bdone, 0));
+    return order_after_unpack(h);
+  }
+  h->ev_pre_valid = false;
   // the z ghost planes must have arrived: order the compute stream after the last unpack
   if (int rc = order_after_unpack(h)) return rc;
   if (!split) return stage_launch(h, dt_stage, space_ooa, is_full_step, 0, nz, true, true);
