@@ -55,6 +55,7 @@ struct StageArgs {
   double glm_damp;    // exp(-FV_dt*chyp*cr), evaluated on the host
   double max_temp;    // EP.MaxTemperature
   int use_march;      // != 0: k_stage_rows2 (3-D, nbc >= 2: production), 0: k_stage (cell per thread; 1-D / 2-D, cross-check)
+  int xwrap;          // k_stage_rows2: x faces periodic -> also write the x ghost images of the rows it updates
   int zslope_lds;     // k_stage_rows2: carry the z slope in LDS (else rebuild it from plane k-1)
   double *dE;         // k_stage_rows2: cooling source PtoU(p_new)[ERG]-PtoU(P)[ERG] per cell from k_cooling_dE (or null)
   int zchunk;         // planes per wavefront in the marching kernels

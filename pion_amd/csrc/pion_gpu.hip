@@ -33,13 +33,15 @@ struct BCArgs {
 // every ghost cell holding the on-grid cell at its coordinates wrapped axis by axis, so the wrapped
 // cell can be read directly: the same values, one launch instead of six.  z faces of kind SLAB
 // (neighbour rank) are left alone: then only ghosts on on-grid z planes are filled.
-__global__ __launch_bounds__(256) void k_bc_periodic_all(double *T, const GridDesc g, const int nvar, const int zwrap)
+__global__ __launch_bounds__(256) void k_bc_periodic_all(double *T, const GridDesc g, const int nvar, const int zwrap,
+                                                         const int skipx)
 {
   // ghost cells as three disjoint slabs: A = z ghosts (all x,y), B = y ghosts on on-grid z (all x),
   // C = x ghosts on on-grid y and z
   const long nA = zwrap ? (long)2 * g.nbc[2] * g.nga[0] * g.nga[1] : 0;
   const long nB = (long)g.ng[2] * 2 * g.nbc[1] * g.nga[0];
-  const long nC = (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
+  // (skipx: the stage kernel has already written the x ghosts of the on-grid rows, slab C)
+  const long nC = skipx ? 0 : (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nA + nB + nC) return;
   int i0, i1, i2;  // all-cell coordinates (ghosts included)
@@ -286,6 +288,7 @@ struct Handle {
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
   int use_march = 3, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
+  const double *xghost_fresh = nullptr;   // array whose x ghosts (periodic x) the last stage kernel wrote itself
   int zslope_lds = 1;     // k_stage_rows2: carry the z slope in LDS (default; PION_ZSLOPE_LDS=0: rebuild it from plane k-1, R = 4)
   double *ddE = nullptr;  // cooling source per cell (k_cooling_dE -> k_stage_rows2)
   bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
@@ -650,6 +653,7 @@ int pion_gpu_ng_all(void *handle, int axis) { return ((Handle *)handle)->g.nga[a
 int pion_gpu_upload(void *handle, const double *P_soa)
 {
   Handle *h = use(handle);
+  h->xghost_fresh = nullptr;
   const size_t nb = sizeof(double) * (size_t)h->cfg.nvar * h->g.ncell;
   HCHECK(h, hipMemcpyAsync(h->dP, P_soa, nb, hipMemcpyHostToDevice, h->stream));
   HCHECK(h, hipMemcpyAsync(h->dPh, h->dP, nb, hipMemcpyDeviceToDevice, h->stream));
@@ -674,6 +678,7 @@ int pion_gpu_download(void *handle, int which, double *P_soa)
 int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh)
 {
   Handle *h = use(handle);
+  h->xghost_fresh = nullptr;
   if (!dP || !dPh) return PION_GPU_EINVAL;
   if (h->own_state) {
     hipFree(h->dP);
@@ -689,6 +694,7 @@ int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh)
 void *pion_gpu_device_ptr(void *handle, int which)
 {
   Handle *h = use(handle);
+  h->xghost_fresh = nullptr;
   h->dt_cached = false;  // the caller may write through the pointer
   return which == 0 ? (void *)h->dP : (void *)h->dPh;
 }
@@ -838,11 +844,14 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
   if (all_periodic && cfg.ndim == 3 && cfg.bc_type[4] != cfg.bc_type[5]) all_periodic = false;
   if (all_periodic) {
     const int zwrap = (cfg.ndim == 3 && cfg.bc_type[4] == PION_BC_PERIODIC) ? 1 : 0;
+    // x ghosts of the on-grid rows: already in place when the stage kernel that wrote T also wrote them
+    const int skipx = (h->xghost_fresh == T) ? 1 : 0;
     const long n = (zwrap ? (long)2 * g.nbc[2] * g.nga[0] * g.nga[1] : 0) + (long)g.ng[2] * 2 * g.nbc[1] * g.nga[0]
-                   + (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
+                   + (skipx ? 0 : (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0]);
     hipLaunchKernelGGL(k_bc_periodic_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, T, g, cfg.nvar,
-                       zwrap);
+                       zwrap, skipx);
   }
+  h->xghost_fresh = nullptr;
   // TimeUpdateExternalBCs in list order XN,XP,YN,YP,ZN,ZP then DMR2 (assign_update_bcs.cpp:185-252)
   for (int d = 0; d < 2 * cfg.ndim && !all_periodic; d++) {
     const int type = cfg.bc_type[d];
@@ -1122,6 +1131,9 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.kz3 = (kz3 > kz2) ? kz3 : kz2;
   a.zslope_lds = h->zslope_lds;
   a.dE = nullptr;
+  // periodic x: k_stage_rows2 writes the x ghost images of its rows (the boundary launch then skips them)
+  a.xwrap = (a.use_march != 0 && h->g.ndim == 3 && h->g.nbc[2] >= 2 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC
+             && cfg.bc_type[1] == PION_BC_PERIODIC && h->g.ng[0] >= 2 * h->g.nbc[0]) ? 1 : 0;
   if (a.use_march == 3 && h->g.ndim == 3)
     a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows)
                            : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows);
@@ -1201,6 +1213,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   }
   h->ph_valid = !is_full_step;
   h->dt_cached = fuse_dt;
+  h->xghost_fresh = a.xwrap ? ((is_full_step && a.out == h->dPh) ? h->dP : a.out) : nullptr;
   return 0;
 }
 

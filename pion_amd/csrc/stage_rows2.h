@@ -558,6 +558,20 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         else cell_update<EQ, NTR>(a, P0, dU, err, Pf, PLAIN);
 #pragma unroll
         for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb, off, Pf[v]);
+        if (a.xwrap) {
+          // periodic x faces: the ghost images of the first / last nbc cells of the row are these same values
+          // (periodic_boundaries.cpp:42-50); written here, where the row is in registers, instead of by the
+          // boundary kernel, whose x slab is one uncoalesced 8-byte access per row and variable
+          const long xs = (long)a.g.ng[0] * 8;
+          if (ix < a.g.nbc[0]) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb + xs, off, Pf[v]);
+          }
+          else if (ix >= a.g.ng[0] - a.g.nbc[0]) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb - xs, off, Pf[v]);
+          }
+        }
         if (a.dtres) {
           // calc_dynamics_dt / calc_microphysics_dt (calc_timestep.cpp:271-507) of the state just
           // written: after a full step it is the state the next step's dt is computed from
