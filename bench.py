@@ -206,6 +206,22 @@ def parity_build_run(args, cfg, device, dt_lim, steps=3, warmup=1):
             "fp_mode": "strict (-ffp-contract=off, reference operation order; bit-identical to the oracle)"}
 
 
+class _stdout_to_stderr:
+    """gloo and RCCL print connection / version banners on fd 1 while a process group or communicator is
+    created; bench.py's stdout carries exactly one JSON line, so fd 1 points at fd 2 meanwhile"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2])
@@ -272,17 +288,21 @@ def main():
     if world > 1 and use_host:
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo")   # bootstrap (ncclUniqueId) and timing barrier only
+        with _stdout_to_stderr():
+            dist.init_process_group("gloo")   # bootstrap (ncclUniqueId) and timing barrier only
+            dist.barrier()
     elif world > 1:
         import torch
         import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            local_rank = local_rank % torch.cuda.device_count()
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo")
+        with _stdout_to_stderr():
+            if args.backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                local_rank = local_rank % torch.cuda.device_count()
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("gloo")
+            dist.barrier()
 
     loopback = args.loopback and world == 1 and args.workload == "m1"
     if loopback and not use_host:
