@@ -465,6 +465,11 @@ def main():
                             "valu_active_frac_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
                             "waitcnt_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
                             "waves_per_simd": 2, "source": "profiles/r02_pmc_sq_stage_kernel.json"}
+                    # the roofline that actually binds: every wave-level VALU instruction of this fp64 kernel holds
+                    # its SIMD's vector pipe for 4 cycles (16 fp64 lanes per clock per SIMD, 78.6 TFLOP/s spec);
+                    # fraction of that issue capacity the launch used, at the nominal 2.4 GHz
+                    if stage_ms > 0:
+                        valu["fp64_issue_frac_at_2.4GHz"] = c["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * stage_ms * 1e-3)
         out = {
             "metric": baseline_metric(),
             "value": value, "unit": "Mcell-updates/s", "n_gpus": world, "steps": args.steps,
