@@ -28,15 +28,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 
 
 def kernel_source_hash():
-    """hash of pion_amd/csrc sources (the same function as profiles/tools/summarize_r02.py)"""
+    """hash of the CODE of pion_amd/csrc (// comments and blank lines dropped, so that a comment edit does not
+    invalidate the committed PMC measurements; the same function as profiles/tools/summarize_r02.py)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pion_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")) or f == "Makefile":
             h.update(f.encode())
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(fh.read())
+            with open(os.path.join(d, f), encoding="utf-8", errors="replace") as fh:
+                for line in fh:
+                    line = re.sub(r"(//|#(?!\s*(include|define|if|else|endif|ifdef|ifndef|undef|pragma|error))).*$", "", line).strip()
+                    if line:
+                        h.update(line.encode())
+                        h.update(b"\n")
     return h.hexdigest()[:16]
 
 

@@ -460,6 +460,9 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   g.cyl = (cfg->coord_sys == 2) ? 1 : ((cfg->coord_sys == 3) ? 2 : 0);
   g.sph_vol = nullptr;
   *handle = h;
+  // k_stage_rows2 (3-D, two ghost layers) addresses every array as "uniform base + 32-bit byte offset of the
+  // cell": grids of 2^29 cells or more (ghosts included) use the cell-per-thread kernel with 64-bit addresses
+  if (!(g.ndim == 3 && g.nbc[2] >= 2 && (unsigned long long)g.ncell * 8ull < (1ull << 32))) h->use_march = 0;
 
   const size_t nb = sizeof(double) * (size_t)cfg->nvar * g.ncell;
   HCHECK(h, hipMalloc(&h->dP, nb));
@@ -1030,7 +1033,7 @@ int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr)
 // part (the nbc on-grid planes next to each z face) waits for the unpacked halo.
 static bool stage_can_split(const Handle *h)
 {
-  return h->use_march >= 2 && h->g.ndim == 3 && h->g.nbc[2] >= 2 && !h->deta
+  return h->use_march != 0 && !h->deta
          && h->g.ng[2] > 2 * h->g.nbc[2] && !(h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1);
 }
 
@@ -1132,9 +1135,9 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.zslope_lds = h->zslope_lds;
   a.dE = nullptr;
   // periodic x: k_stage_rows2 writes the x ghost images of its rows (the boundary launch then skips them)
-  a.xwrap = (a.use_march != 0 && h->g.ndim == 3 && h->g.nbc[2] >= 2 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC
+  a.xwrap = (a.use_march != 0 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC
              && cfg.bc_type[1] == PION_BC_PERIODIC && h->g.ng[0] >= 2 * h->g.nbc[0]) ? 1 : 0;
-  if (a.use_march == 3 && h->g.ndim == 3)
+  if (a.use_march != 0)
     a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows)
                            : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows);
   if (a.zchunk <= 0) {
@@ -1166,7 +1169,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
       }
     }
   }
-  if (cfg.cooling != 0 && a.use_march == 3 && h->g.ndim == 3 && h->g.nbc[2] >= 2) {
+  if (cfg.cooling != 0 && a.use_march != 0) {
     // calc_noRT_microphysics_dU as its own launch (thread per cell, full occupancy): dE per cell
     a.dE = h->ddE;
     time_begin(h, 1);
@@ -1179,7 +1182,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   }
   // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
   // (second-order stages only: the first-order instances of k_stage_rows carry no reduction code)
-  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march >= 2 && h->g.ndim == 3
+  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march != 0 && h->g.ndim == 3
                        && h->g.nbc[2] >= 2 && a.out == h->dP;
   a.dtres = nullptr;
   a.cfl = cfg.cfl;

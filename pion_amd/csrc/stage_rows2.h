@@ -29,7 +29,7 @@
 // folded into the scalar base, the x neighbours into the instruction's immediate offset, and the one
 // per-lane quantity -- the cell -- is a single VGPR per row.  (With 64-bit per-lane addresses the compiler
 // hoists one VGPR pair per load site out of the task loop: ~80 registers, which do not exist here.)
-// Needs 8 * ncell < 2^32 (checked by the launcher; 512^3 with ghosts is 1.1e9).
+// Needs 8 * ncell < 2^32 (pion_gpu_create picks the cell-per-thread kernel otherwise; 512^3 with ghosts is 1.1e9).
 // (readfirstlane keeps the optimiser from re-associating base + offset into per-lane 64-bit arithmetic; on a
 // value that already lives in SGPRs it costs nothing.  The access is made through an address_space(1)
 // pointer so that it stays a global_ instruction after the integer round trip.)

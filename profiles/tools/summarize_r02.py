@@ -19,12 +19,19 @@ PROF = os.path.join(ROOT, "profiles")
 
 
 def kernel_source_hash():
+    """the same function as bench.py's (code only: // comments and blank lines dropped)"""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "pion_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".h", ".hip")) or f == "Makefile":
             h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+            with open(os.path.join(d, f), encoding="utf-8", errors="replace") as fh:
+                for line in fh:
+                    line = re.sub(r"(//|#(?!\s*(include|define|if|else|endif|ifdef|ifndef|undef|pragma|error))).*$", "", line).strip()
+                    if line:
+                        h.update(line.encode())
+                        h.update(b"\n")
     return h.hexdigest()[:16]
 
 
