@@ -59,10 +59,10 @@ struct StageArgs {
   int zslope_lds;     // k_stage_rows2: carry the z slope in LDS (else rebuild it from plane k-1)
   double *dE;         // k_stage_rows2: cooling source PtoU(p_new)[ERG]-PtoU(P)[ERG] per cell from k_cooling_dE (or null)
   int zchunk;         // planes per wavefront in the marching kernels
-  int rows;           // y-rows per wavefront in k_stage_rows
-  int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows; others: whole grid)
+  int rows;           // y-rows per wavefront in k_stage_rows2
+  int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows2; k_stage: whole grid)
   int kz2, kz3;       // and a second strip [kz2,kz3) (empty when kz3 <= kz2): the two z-boundary strips
-  unsigned long long *dtres;  // k_stage_rows, full step: min t_dyn / t_mp bits of the new state (or null)
+  unsigned long long *dtres;  // k_stage_rows2, full step: min t_dyn / t_mp bits of the new state (or null)
   double cfl;
   int dt_mp;          // also reduce the cooling time (EP.MP_timestep_limit)
   CoolDev cool;

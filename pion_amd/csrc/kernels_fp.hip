@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_stage(const StageArgs a)
     double d[NV];
     to_sweep<NV, MHD>(ax, dU, d);
 #ifdef PION_FAST_MATH
-    // fast build, Cartesian axis: the same regrouped source + flux-difference update as k_stage_rows
+    // fast build, Cartesian axis: the same regrouped source + flux-difference update as k_stage_rows2
     // (apply_axis), so that the two kernels agree to rounding
     const bool fast_cart = !cylR && !sphR;
 #else

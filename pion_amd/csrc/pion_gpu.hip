@@ -957,7 +957,7 @@ int pion_gpu_calc_dt_device(void *handle, void **dptr)
     return PION_GPU_EINVAL;
   }
   if (!h->dt_cached) {
-    // (after a full step through k_stage_rows the minima of the new state are already in ddt)
+    // (after a full step through k_stage_rows2 the minima of the new state are already in ddt)
     HCHECK(h, hipMemcpyAsync(h->ddt, h->ddt_init, 2 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     time_begin(h, 3);
     const int rc = h->cfg.strict_fp ? fp_strict::launch_dt(a, h->stream) : fp_fast::launch_dt(a, h->stream);
@@ -1181,7 +1181,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     }
   }
   // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
-  // (second-order stages only: the first-order instances of k_stage_rows carry no reduction code)
+  // (second-order stages only: the first-order instances of k_stage_rows2 carry no reduction code)
   const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march != 0 && h->g.ndim == 3
                        && h->g.nbc[2] >= 2 && a.out == h->dP;
   a.dtres = nullptr;

@@ -100,7 +100,7 @@ PDEV void cell_update(const StageArgs &a, const double *P0, const double *dU, in
   const double g = a.fc.gamma;
   double u1[NV];
   MPd mp = a.fc.mp;
-  if (no_mp) mp.present = false;  // compile-time constant in the PLAIN instances of k_stage_rows
+  if (no_mp) mp.present = false;  // compile-time constant in the PLAIN instances of k_stage_rows2
   if (mp.present) {
     double Pi[NV];
 #pragma unroll

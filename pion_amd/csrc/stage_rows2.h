@@ -3,7 +3,7 @@
 // Included by kernels_fp.hip inside namespace pion::PION_FPNS (after stage_march.h and stage_rows.h,
 // whose helpers load_rot / slope3 / apply_axis / cell_update_store / cell_dt / rows_tiling it reuses).
 //
-// Same decomposition as k_stage_rows (one wavefront per x-pencil of 64 lanes owning R consecutive
+// Same decomposition as round 1's k_stage_rows (removed; one wavefront per x-pencil of 64 lanes owning R consecutive
 // y-rows, marching along z; x fluxes shared by wavefront shuffles, the y flux and the next row's y slope
 // carried from row to row in registers, the z-carried state of every row in LDS) rebuilt around the
 // round-1 profile: that kernel needed 500 registers (one wavefront per SIMD), spent 22 % of its wave

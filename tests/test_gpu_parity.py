@@ -255,7 +255,7 @@ def test_every_mhd_instantiation_3d(eq, solver, ntr, strict, monkeypatch):
 @pytest.mark.parametrize("strict", [1, 0])
 @pytest.mark.parametrize("case", ["hd", "mhd", "glm", "wind"])
 def test_fused_dt_equals_dt_kernel(case, strict):
-    """the full stage of k_stage_rows leaves (t_dyn, t_mp) of the new state behind; it must be what
+    """the full stage of k_stage_rows2 leaves (t_dyn, t_mp) of the new state behind; it must be what
     k_dt computes from that state (calc_timestep.cpp:271-507)"""
     from pion_amd import cooling
     setup = None
@@ -294,8 +294,8 @@ def test_fused_dt_equals_dt_kernel(case, strict):
 @pytest.mark.parametrize("ntr", [0, 1, 2])
 @pytest.mark.parametrize("eq", [abi.EQMHD, abi.EQGLM])
 def test_hlld_with_hcorrection_instances_3d(eq, ntr, strict, monkeypatch):
-    """the HLLD instances of k_stage_rows exist twice (with and without the H-correction / microphysics
-    code, see stage_rows_go); the blast tests above run the plain ones, this one the others"""
+    """the HLLD instances of k_stage_rows2 exist twice (with and without the H-correction / microphysics
+    code, see stage_rows2_go_z); the blast tests above run the plain ones, this one the others"""
     cfg0, P0 = problems.mhd_blastwave(14, 3, eq, abi.FLUX_RS_HLLD, strict_fp=strict)
     cfg0.artvisc = abi.AV_HCORR_FKJ98
     cfg, P = _with_tracers(cfg0, P0, ntr)
@@ -311,7 +311,7 @@ def test_hlld_with_hcorrection_instances_3d(eq, ntr, strict, monkeypatch):
 @pytest.mark.parametrize("strict", [1, 0])
 @pytest.mark.parametrize("ntr", [0, 1, 2])
 def test_hd_roe_with_hcorrection_instances_3d(ntr, strict, monkeypatch):
-    """Euler Roe-CV is specialised like MHD HLLD (stage_rows_go): the non-plain instances"""
+    """Euler Roe-CV is specialised like MHD HLLD (stage_rows2_go_z): the non-plain instances"""
     cfg0, P0 = problems.hd_blast_octant(14, 3, solver=abi.FLUX_RSroe, artvisc=abi.AV_HCORR_FKJ98, strict_fp=strict,
                                         nzones=3.0)
     cfg, P = _with_tracers(cfg0, P0, ntr)

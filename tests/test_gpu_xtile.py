@@ -1,7 +1,7 @@
 """The full 62-cell x-tile path of the 3-D stage kernel against the ORACLE.
 
 Every other oracle-compared 3-D grid has nx <= 48, i.e. only the packed remainder wavefront of
-k_stage_rows runs.  Here nx = 70 (one full tile + an 8-cell remainder) and nx = 130 (two full tiles + a
+k_stage_rows2 runs.  Here nx = 70 (one full tile + an 8-cell remainder) and nx = 130 (two full tiles + a
 6-cell remainder), ny not a multiple of the rows per wavefront, and data with gradients across every
 tile seam.  Strict build: bit-exact.  Fast (benchmarked) build: cell-wise within 1e-11 of each
 variable's scale per step, on problems where the reference itself is well conditioned
