@@ -92,3 +92,80 @@ def test_gpu_fast_build_end_state_norms(gold, name):
     else:
         pytest.fail("fast build took %d steps to t = %.17g, reference %d to %.17g" % (
             n, t, int(gold[name + "_n"]), float(gold[name + "_t"])))
+
+
+# ---- config 5 (Wind3D + cooling) at low resolution: no reference fixture can exist (the cooling tables need GSL,
+# "parity unpinned"), so the yardstick is the oracle run on the same inputs -----------------------
+def _wind_setup():
+    from pion_amd import cooling, problems
+    cfg, P, (idx, st), dtl = problems.wind3d(32, strict_fp=1)
+    T, tabs, sl = cooling.build_tables(cfg.min_temp, cfg.max_temp)
+
+    def setup(s):
+        s.set_cooling_tables(T, tabs, sl)
+        s.set_wind_cells(idx, st)
+    return cfg, P, setup, dtl
+
+
+def _wind_run(sim, cfg, P, setup, dtl, nsteps):
+    from pion_amd import driver
+    setup(sim)
+    sc = driver.SimControl(sim, cfg)
+    sc.first_step_dt_limit = dtl
+    sc.init(P)
+    dts = []
+    for _ in range(nsteps):
+        dts.append(sc.calculate_timestep())
+        sc.advance_time()
+    return np.array(dts), sim.download(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strict", [1, 0])
+def test_gpu_wind3d_32_sixty_steps_vs_oracle(strict):
+    """Wind3D single level 32^3 (Euler + tracer, FVS, cooling 8 with the cooling-time limit, stellar-wind cells,
+    reflecting / one-way boundaries), 60 steps: strict build = oracle bit for bit (every dt, the end state);
+    fast build: L1 / L2 <= 1e-10 x refvec.  PARITY UNPINNED against the reference (oracle only)."""
+    from cpu_backends import CpuSim
+    from pion_amd import lib
+    cfg, P, setup, dtl = _wind_setup()
+    with CpuSim(cfg, "orc") as o:
+        dto, Ao = _wind_run(o, cfg, P, setup, dtl, 60)
+    cfg.strict_fp = strict
+    with lib.GpuSim(cfg, 0) as g:
+        dtg, Ag = _wind_run(g, cfg, P, setup, dtl, 60)
+    if strict:
+        assert np.array_equal(dtg, dto)
+        assert np.array_equal(Ag, Ao)
+    else:
+        assert np.allclose(dtg, dto, rtol=1e-9, atol=0.0)
+        l1, l2, mx = gc.diff_norms(cfg, Ag, Ao)
+        assert l1.max() <= 1e-10 and l2.max() <= 1e-10, (l1, l2, mx)
+
+
+@pytest.mark.gpu
+def test_gpu_long_run_256cubed_stays_physical_and_conserves():
+    """the benchmark problem at 256^3 for 120 steps (the blast reaches the periodic faces): finite, positive,
+    mass conserved to rounding, the fast build's conserved totals within 1e-10 of the strict build's"""
+    from pion_amd import driver, lib, problems
+    tot = {}
+    for strict in (1, 0):
+        cfg, _ = problems.mhd_blastwave(4, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=strict)
+        cfg.ng[0] = cfg.ng[1] = cfg.ng[2] = 256
+        cfg.dx = 1.0 / 256
+        P = problems.fill_mhd_blastwave(cfg)
+        m0 = P[0, 2:-2, 2:-2, 2:-2].sum()
+        with lib.GpuSim(cfg, 0) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            del P
+            sc.time_int(120)
+            A = g.download(0)
+        inner = A[:, 2:-2, 2:-2, 2:-2]
+        assert np.isfinite(inner).all()
+        assert inner[0].min() > 0 and inner[1].min() > 0
+        assert abs(inner[0].sum() - m0) <= 1e-10 * m0
+        tot[strict] = gc.conserved_totals(cfg, A)
+        del A, inner
+    rel = np.abs(tot[0][0] - tot[1][0]) / (tot[1][1] + 1e-300)
+    assert rel.max() <= 1e-10, rel
