@@ -24,6 +24,10 @@
 #ifndef PION_STAGE_ROWS2_H
 #define PION_STAGE_ROWS2_H
 
+#ifndef PION_ROWS2_NT
+#define PION_ROWS2_NT 1   // non-temporal stores of the new state / loads of the once-read start-of-step state (25.35-25.43 vs 25.5-25.6 ms/step; 2 = also the z planes: 25.52)
+#endif
+
 // Addressing: every global access of the kernel is "uniform base + 32-bit per-lane byte offset"
 // (global_load ... v_off, s[base:base+1]): the variable, the neighbour shift along y / z and the array are
 // folded into the scalar base, the x neighbours into the instruction's immediate offset, and the one
@@ -55,7 +59,22 @@ PDEV void stu(char *ubase, const unsigned off, const double x)
 {
   typedef __attribute__((address_space(1))) char *gc;
   typedef __attribute__((address_space(1))) double *gp;
+#if PION_ROWS2_NT
+  __builtin_nontemporal_store(x, (gp)((gc)uni(ubase) + off));   // written once, read by the next launch
+#else
   *(gp)((gc)uni(ubase) + off) = x;
+#endif
+}
+// a value that is read exactly once by the launch (the start-of-step state of the second-order stage)
+PDEV double ldu_once(const char *ubase, const unsigned off)
+{
+  typedef const __attribute__((address_space(1))) char *gc;
+  typedef const __attribute__((address_space(1))) double *gp;
+#if PION_ROWS2_NT
+  return __builtin_nontemporal_load((gp)((gc)uni(ubase) + off));
+#else
+  return *(gp)((gc)uni(ubase) + off);
+#endif
 }
 // an SGPR zero the optimiser cannot see through: added to an array base inside a task it keeps the
 // (loop-invariant) scalar address arithmetic of that task from being hoisted out of the row / plane loops,
@@ -71,7 +90,13 @@ template <int NV, bool MHD>
 PDEV void load_rot2(const char *Sb, const long ncb, const int ax, const long sh, const unsigned off, double *q)
 {
 #pragma unroll
-  for (int s = 0; s < NV; s++) q[s] = ldu(Sb + (long)rotvar<MHD>(ax, s) * ncb + sh, off);
+  for (int s = 0; s < NV; s++) {
+#if PION_ROWS2_NT >= 2
+    if (ax == 2) q[s] = ldu_once(Sb + (long)rotvar<MHD>(ax, s) * ncb + sh, off);   // z planes: streamed
+    else
+#endif
+      q[s] = ldu(Sb + (long)rotvar<MHD>(ax, s) * ncb + sh, off);
+  }
 }
 
 // SetSlope x dx for one cell from its two neighbours (VectorOps.cpp:578-617, AvgFalle :37-59): the edge
@@ -549,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         }
         else {
 #pragma unroll
-          for (int v = 0; v < NV; v++) P0[v] = ldu(reinterpret_cast<const char *>(a.Pc) + v * ncb, off);
+          for (int v = 0; v < NV; v++) P0[v] = ldu_once(reinterpret_cast<const char *>(a.Pc) + v * ncb, off);
         }
         if (!(fl & 4) || !(fl & 16)) {
 #pragma unroll
