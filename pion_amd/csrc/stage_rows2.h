@@ -85,6 +85,16 @@ PDEV unsigned opaque_zero()
   asm volatile("s_mov_b32 %0, 0" : "=s"(z));
   return z;
 }
+// The per-lane offset as the block that uses it sees it.  Instruction selection works one basic block at a time
+// and folds "uniform base + zext(32-bit lane offset)" into the scalar-base form of a global access
+// (global_load v, v_off, s[base:base+1]) only when the zero-extension is in the block of the access; the
+// optimiser otherwise keeps ONE 64-bit copy of the offset per row (hoisted) and every access pays a 64-bit
+// VALU add (v_lshl_add_u64) for its address.  An empty volatile asm re-defines the offset inside the block.
+PDEV unsigned pin_v(unsigned x)
+{
+  asm volatile("" : "+v"(x));
+  return x;
+}
 // sweep-frame state of the cell at uniform byte shift `sh` from the lane's cell
 template <int NV, bool MHD>
 PDEV void load_rot2(const char *Sb, const long ncb, const int ax, const long sh, const unsigned off, double *q)
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
   for (int r = 0; r < nrows; r++) {
     if constexpr (ZSL) {
       const long c = crow0 + sy * ((r < nrows_l) ? r : nrows_l - 1);
-      const unsigned off = (unsigned)c * 8u;
+      const unsigned off = pin_v((unsigned)c * 8u);
       double qa[NV], qb[NV], qc[NV], s[NV];
       load_rot2<NV, MHD>(Sb, ncb, 2, -szb, off, qa);
       load_rot2<NV, MHD>(Sb, ncb, 2, 0, off, qb);
@@ -247,26 +257,27 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
     for (int r = 0; r < nrows; r++) {
       const bool row_ok = (r < nrows_l);
       const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
-      const unsigned off = (unsigned)c * 8u, offb = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
+      const unsigned off_r = (unsigned)c * 8u, offb_r = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
       // the row visited after this one (next row of the plane, or the first row of the next plane)
       const long cn = (r + 1 < nrows) ? crow0 + sy * ((r + 1 < nrows_l) ? r + 1 : nrows_l - 1) + sz * (k - (k0 - 1))
                                       : crow0 + sz * (k + 1 - (k0 - 1));
-      const unsigned offn = (unsigned)cn * 8u, offnb = (unsigned)cn;
+      const unsigned offn_r = (unsigned)cn * 8u, offnb_r = (unsigned)cn;
       double q0[NV], dU[NV];
       if (PF && !prime) {
 #pragma unroll
         for (int v = 0; v < NV; v++) q0[v] = pf[v];   // requested before the previous row's last solve
       }
       else {
+        const unsigned o = pin_v(off_r);
 #pragma unroll
-        for (int v = 0; v < NV; v++) q0[v] = ldu(Sb + v * ncb, off);
+        for (int v = 0; v < NV; v++) q0[v] = ldu(Sb + v * ncb, o);
       }
 #pragma unroll
       for (int v = 0; v < NV; v++) dU[v] = 0.0;
       if (!PLAIN && !prime && a.dE) {
         // calc_noRT_microphysics_dU (time_integrator.cpp:438-489): only the energy changes; k_cooling
         // left PtoU(p_new)[ERG] - PtoU(P)[ERG] of every domain cell (0 elsewhere)
-        dU[uERG] += ldu(reinterpret_cast<const char *>(a.dE), off);
+        dU[uERG] += ldu(reinterpret_cast<const char *>(a.dE), pin_v(off_r));
       }
       double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;
 
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         const unsigned zt = opaque_zero();
         const char *const St = Sb + zt, *const Ht = Hb + zt;
         if (t == 0) {
+          const unsigned off = pin_v(off_r), offb = pin_v(offb_r);   // (pin_v: offsets as this block sees them)
           ax = 0;
           st = 1;
           cl = c;
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         }
         else if (t == 1) {
           // first row of the group: lower y face (c-sy | c); slopes of rows j-1 and j
+          const unsigned off = pin_v(off_r), offb = pin_v(offb_r);   // (pin_v: offsets as this block sees them)
           ax = 1;
           st = sy;
           cl = c - sy;
@@ -373,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         else if (t == 2) {
           // upper y face (c | c+sy): this row's slope is ysn (from the lower face or the previous row),
           // the next row's slope is new and replaces it
+          const unsigned off = pin_v(off_r), offb = pin_v(offb_r);   // (pin_v: offsets as this block sees them)
           ax = 1;
           st = sy;
           cl = c;
@@ -423,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         }
         else {
           // upper z face (c | c+sz)
+          const unsigned off = pin_v(off_r), offb = pin_v(offb_r);   // (pin_v: offsets as this block sees them)
           ax = 2;
           st = sz;
           cl = c;
@@ -490,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
           // requests for the task that follows this solve
           const unsigned zp = opaque_zero();
           const char *const Sp = Sb + zp, *const Hp = Hb + zp;
+          const unsigned off = pin_v(off_r), offb = pin_v(offb_r), offn = pin_v(offn_r), offnb = pin_v(offnb_r);
           if (t == 3) {
             // next: the x task of the next row; in the priming plane, where every row runs the z task
             // only, the z task of the next row (after its last row: the x task of the first row of the
@@ -566,7 +582,13 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
       }
 
       if (!prime && writer && row_ok) {
-        const unsigned fl = ldub(reinterpret_cast<const char *>(a.flags) + opaque_zero(), offb);
+        const unsigned off = pin_v(off_r), offb = pin_v(offb_r);
+        // (array bases made opaque here for the same reason as in the tasks: computed by the scalar unit in this
+        // block instead of hoisted out of the loops, spilled to VGPR lanes and read back by VALU v_readlane)
+        const unsigned zu = opaque_zero();
+        const char *const Pcb = reinterpret_cast<const char *>(a.Pc) + zu;
+        char *const Ob = reinterpret_cast<char *>(a.out) + zu;
+        const unsigned fl = ldub(reinterpret_cast<const char *>(a.flags) + zu, offb);
         double P0[NV], Pf[NV];
         if (same_pc) {
 #pragma unroll
@@ -574,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         }
         else {
 #pragma unroll
-          for (int v = 0; v < NV; v++) P0[v] = ldu_once(reinterpret_cast<const char *>(a.Pc) + v * ncb, off);
+          for (int v = 0; v < NV; v++) P0[v] = ldu_once(Pcb + v * ncb, off);
         }
         if (!(fl & 4) || !(fl & 16)) {
 #pragma unroll
@@ -582,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
         }
         else cell_update<EQ, NTR>(a, P0, dU, err, Pf, PLAIN);
 #pragma unroll
-        for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb, off, Pf[v]);
+        for (int v = 0; v < NV; v++) stu(Ob + v * ncb, off, Pf[v]);
         if (a.xwrap) {
           // periodic x faces: the ghost images of the first / last nbc cells of the row are these same values
           // (periodic_boundaries.cpp:42-50); written here, where the row is in registers, instead of by the
@@ -590,11 +612,11 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
           const long xs = (long)a.g.ng[0] * 8;
           if (ix < a.g.nbc[0]) {
 #pragma unroll
-            for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb + xs, off, Pf[v]);
+            for (int v = 0; v < NV; v++) stu(Ob + v * ncb + xs, off, Pf[v]);
           }
           else if (ix >= a.g.ng[0] - a.g.nbc[0]) {
 #pragma unroll
-            for (int v = 0; v < NV; v++) stu(reinterpret_cast<char *>(a.out) + v * ncb - xs, off, Pf[v]);
+            for (int v = 0; v < NV; v++) stu(Ob + v * ncb - xs, off, Pf[v]);
           }
         }
         if (a.dtres) {
