@@ -16,7 +16,6 @@ namespace pion {
 #define PION_MAX_NTR 2
 // LDS a workgroup of k_stage_rows2 may use so that two fit a CU (160 KiB)
 #define PION_ROWS2_LDS_BYTES (80 * 1024)
-#define PION_ROWS2_SCRATCH_BYTES 256   // landing area of the L2 requests (stage_rows2.h: l2_request)
 #define PION_COOL_NT_MAX 256
 
 struct GridDesc {

@@ -696,7 +696,7 @@ int stage_rows2_rows(int eq, int ntr, int zslope_lds, int want)
 {
   const int nv = ((eq == EQEUL) ? 5 : ((eq == EQMHD) ? 8 : 9)) + ntr;
   const int nz = zslope_lds ? 2 * nv : nv;
-  int r = (int)((PION_ROWS2_LDS_BYTES - PION_ROWS2_SCRATCH_BYTES) / (sizeof(double) * 4 * nz * 64));
+  int r = (int)(PION_ROWS2_LDS_BYTES / (sizeof(double) * 4 * nz * 64));
   if (r > 8) r = 8;
   if (want < r) r = want;
   return r < 1 ? 1 : r;

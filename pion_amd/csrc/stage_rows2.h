@@ -95,24 +95,6 @@ PDEV unsigned pin_v(unsigned x)
   asm volatile("" : "+v"(x));
   return x;
 }
-// Request without a destination register: the 64 cells of a row (four 128-byte lines) are brought into L2 / L1 by
-// one load-to-LDS instruction (4 bytes per lane, dropped into a 256-byte scratch area of LDS).  Issued before a
-// Riemann solve for what the task AFTER it will read, so that those reads find their lines on the chip: the
-// second-order instances have no registers to hold anything across a solve, and with two wavefronts per SIMD
-// a task's first-touch reads otherwise wait out the full HBM latency with nothing in flight behind them.
-PDEV void l2_request(const char *ubase, const unsigned off, double *scratch)
-{
-  typedef const __attribute__((address_space(1))) char *gc;
-  typedef __attribute__((address_space(3))) void *lp;
-  __builtin_amdgcn_global_load_lds((gc)uni(ubase) + off, (lp)scratch, 4, 0, 0);
-}
-template <int NV>
-PDEV void l2_request_row(const char *Sb, const long ncb, const long sh, const unsigned off_, double *scratch)
-{
-  const unsigned off = pin_v(off_);   // (callers sit in their own conditional blocks)
-#pragma unroll
-  for (int v = 0; v < NV; v++) l2_request(Sb + v * ncb + sh, off, scratch);
-}
 // sweep-frame state of the cell at uniform byte shift `sh` from the lane's cell
 template <int NV, bool MHD>
 PDEV void load_rot2(const char *Sb, const long ncb, const int ax, const long sh, const unsigned off, double *q)
@@ -150,9 +132,6 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #ifndef PION_ROWS2_PF
 #define PION_ROWS2_PF 1
 #endif
-#ifndef PION_ROWS2_L2PF
-#define PION_ROWS2_L2PF 0   // 1: second-order instances request the next task's rows into L2 before each solve (l2_request).  Measured: 13.8 -> 16.5 ms per launch (+60 % VMEM instructions); the kernel is not latency-bound
-#endif
 #ifndef PION_ROWS2_YWG
 #define PION_ROWS2_YWG 1
 #endif
@@ -166,7 +145,6 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
   constexpr bool MHD = E::MHD;
   constexpr int NZ = ZSL ? 2 * NV : NV;   // LDS slots per row: [z slope,] lower z flux
   constexpr bool PF = PION_ROWS2_PF && (OAMODE == 1);
-  constexpr bool L2PF = PION_ROWS2_L2PF && !PF;
   extern __shared__ double lds[];
 
   const int R = a.rows;
@@ -230,7 +208,6 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
   int err = 0;
   double tdyn = 1.e100, tmp = 1.0e99;  // running minima for the fused time-step reduction
 
-  double *const scratch = lds + 4 * R * NZ * 64;   // (uniform; every wavefront's requests land on the same 256 bytes)
   const int zbase = wave * R * NZ * 64 + lane;
 #define ZS2(r, s) lds[zbase + ((r) * NZ + (s)) * 64]
 
@@ -568,31 +545,6 @@ __global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
             if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offb) | ldub(Hp + sz, offb);
           }
         }
-        if (L2PF && !prime) {
-          // what the task after this solve reads for the first time
-          const unsigned zp = opaque_zero();
-          const char *const Sp = Sb + zp;
-          const unsigned off = pin_v(off_r);
-          if (t == 0) {
-            if (r == 0) {
-              l2_request_row<NV>(Sp, ncb, -syb, off, scratch);
-              if (oa2) l2_request_row<NV>(Sp, ncb, -2 * syb, off, scratch);
-            }
-            l2_request_row<NV>(Sp, ncb, syb, off, scratch);
-            if (oa2 && r > 0) l2_request_row<NV>(Sp, ncb, 2 * syb, off, scratch);
-          }
-          else if (t == 1) {
-            if (oa2) l2_request_row<NV>(Sp, ncb, 2 * syb, off, scratch);
-          }
-          else if (t == 2) {
-            l2_request_row<NV>(Sp, ncb, szb, off, scratch);
-            if (oa2) l2_request_row<NV>(Sp, ncb, 2 * szb, off, scratch);
-          }
-          else {
-            if (!same_pc) l2_request_row<NV>(reinterpret_cast<const char *>(a.Pc) + zp, ncb, 0, off, scratch);
-            if (r + 1 == nrows) l2_request_row<NV>(Sp, ncb, 0, pin_v(offn_r), scratch);
-          }
-        }
         FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 
         if (t == 0) {
@@ -700,7 +652,7 @@ template <int NV, bool ZSL>
 __host__ inline int rows2_rmax()
 {
   constexpr int NZ = ZSL ? 2 * NV : NV;
-  int r = (int)((PION_ROWS2_LDS_BYTES - PION_ROWS2_SCRATCH_BYTES) / (sizeof(double) * 4 * NZ * 64));
+  int r = (int)(PION_ROWS2_LDS_BYTES / (sizeof(double) * 4 * NZ * 64));
   return r > 8 ? 8 : r;
 }
 
@@ -717,7 +669,7 @@ static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
   const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)rows_tiling(a).per_chunk * nzc;
   const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
-  const size_t shmem = sizeof(double) * 4 * R * NZ * 64 + PION_ROWS2_SCRATCH_BYTES;
+  const size_t shmem = sizeof(double) * 4 * R * NZ * 64;
   // compile-time spatial order and "no H-correction / microphysics" for the production instances
   // (MHD HLLD, Euler Roe-CV, Euler FVS), run-time for the others
   constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)

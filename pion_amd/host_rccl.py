@@ -27,6 +27,9 @@ def load_host_library():
     if not os.path.exists(path):
         raise ImportError("%s not found: build it with `make -C pion_amd/host`" % path)
     abi.share_torch_hip_runtime()
+    # libpion_host.so NEEDs "libpion_gpu.so" (soname): load the library this process is meant to use first, so
+    # that an alternative build named by PION_GPU_LIB (A/B runs) also serves the C++ time loop
+    C.CDLL(abi.library_path(), mode=C.RTLD_GLOBAL)
     h = C.CDLL(path)
     h.pion_host_sim_create.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.POINTER(C.c_void_p)]
     h.pion_host_sim_destroy.argtypes = [C.c_void_p]
