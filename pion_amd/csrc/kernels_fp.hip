@@ -698,7 +698,18 @@ int stage_rows2_rows(int eq, int ntr, int zslope_lds, int want)
   const int nz = zslope_lds ? 2 * nv : nv;
   int r = (int)(PION_ROWS2_LDS_BYTES / (sizeof(double) * 4 * nz * 64));
   if (r > 8) r = 8;
-  if (want < r) r = want;
+  if (want <= 0) {
+    // automatic.  The MHD instances need the whole register file of two wavefronts per SIMD: as many rows as two
+    // workgroups' LDS allows (fewer Riemann solves per cell).  The Euler instances take ~160 registers, so a
+    // THIRD wavefront per SIMD fits if three workgroups' LDS does: rows for 160 KiB / 3 (measured at 512^3,
+    // second-order stage with 2 rows instead of 4: Roe-CV 13.8 -> 12.8 ms/step, FVS + tracer + cooling 25.9 -> 23.6)
+    if (eq == EQEUL) {
+      int r3 = (int)((160 * 1024 / 3) / (sizeof(double) * 4 * nz * 64));
+      if (r3 < 1) r3 = 1;
+      if (r3 < r) r = r3;
+    }
+  }
+  else if (want < r) r = want;
   return r < 1 ? 1 : r;
 }
 int launch_flux_test(const FluxTestArgs &a, hipStream_t s)

@@ -287,7 +287,8 @@ struct Handle {
   bool timing = false;
   std::vector<hipEvent_t> ev[4];
   double Mu_tot_over_kB = 0.0;
-  int use_march = 3, zchunk = 0, rows = 4;  // zchunk 0: chosen per launch
+  int use_march = 3, zchunk = 0, rows = 0;  // zchunk 0: chosen per launch; rows 0: chosen per instance (stage_rows2_rows)
+  int rows1 = 0;                            // rows of the first-order stage (PION_ROWS1)
   const double *xghost_fresh = nullptr;   // array whose x ghosts (periodic x) the last stage kernel wrote itself
   int zslope_lds = 1;     // k_stage_rows2: carry the z slope in LDS (default; PION_ZSLOPE_LDS=0: rebuild it from plane k-1, R = 4)
   double *ddE = nullptr;  // cooling source per cell (k_cooling_dE -> k_stage_rows2)
@@ -433,7 +434,8 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (const char *e = getenv("PION_CONCURRENT_STRIPS")) h->concurrent_strips = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
-  if (const char *e = getenv("PION_ROWS")) h->rows = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 2;
+  if (const char *e = getenv("PION_ROWS")) h->rows = h->rows1 = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
+  if (const char *e = getenv("PION_ROWS1")) h->rows1 = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
   if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 0;
   h->device = device;
   if (hipSetDevice(device) != hipSuccess) {
@@ -1138,8 +1140,8 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.xwrap = (a.use_march != 0 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC
              && cfg.bc_type[1] == PION_BC_PERIODIC && h->g.ng[0] >= 2 * h->g.nbc[0]) ? 1 : 0;
   if (a.use_march != 0)
-    a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows)
-                           : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, h->rows);
+    a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, space_ooa == 2 ? h->rows : h->rows1)
+                           : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, space_ooa == 2 ? h->rows : h->rows1);
   if (a.zchunk <= 0) {
     // Planes per wavefront.  Every wavefront takes (zchunk + 1 priming plane) plane visits and a CU holds 8
     // wavefronts at a time; pick the chunk that minimises the launch cost model below.

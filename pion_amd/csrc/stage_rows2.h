@@ -136,8 +136,12 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #define PION_ROWS2_YWG 1
 #endif
 
+// workgroups per CU the register allocation aims at
+#ifndef PION_ROWS2_MINWG
+#define PION_ROWS2_MINWG(EQ) 2
+#endif
 template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN, bool ZSL>
-__global__ __launch_bounds__(256, 2) void k_stage_rows2(const StageArgs a)
+__global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const StageArgs a)
 {
   typedef Eqn<EQ, NTR> E;
   typedef Flux<EQ, NTR, SOLVER> FX;
