@@ -509,45 +509,63 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           // requests for the task that follows this solve
           const unsigned zp = opaque_zero();
           const char *const Sp = Sb + zp, *const Hp = Hb + zp;
-          const unsigned off = pin_v(off_r), offb = pin_v(offb_r), offn = pin_v(offn_r), offnb = pin_v(offnb_r);
+          // One load sequence for all cases, steered by uniform quantities (sweep axis of the rotation, row / plane
+          // shift, which of the two cell offsets): written as loads inside the branches the optimiser merges them
+          // into "load (phi of per-lane addresses)", i.e. 64-bit VALU address arithmetic per load.
+          int pax;             // sweep axis whose frame the state is loaded in (0: natural order)
+          long psh, bsh = 0;   // byte shift of the row to load; of the lower neighbour's B_n / psi
+          long hs1, hs2;       // the two switch flags
+          bool wb = true, nextcell = false;
           if (t == 3) {
             // next: the x task of the next row; in the priming plane, where every row runs the z task
             // only, the z task of the next row (after its last row: the x task of the first row of the
             // next plane)
+            nextcell = true;
             if (prime && r + 1 < nrows) {
-              load_rot2<NV, MHD>(Sp, ncb, 2, szb, offn, pf);
-              if constexpr (MHD) {
-                pfb = ldu(Sp + (long)rotvar<MHD>(2, qBN) * ncb - szb, offn);
-                if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb - szb, offn);
-              }
-              if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offnb) | ldub(Hp + sz, offnb);
+              pax = 2;
+              psh = szb;
+              bsh = -szb;
+              hs1 = 0;
+              hs2 = sz;
             }
             else {
-#pragma unroll
-              for (int v = 0; v < NV; v++) pf[v] = ldu(Sp + v * ncb, offn);
-              if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offnb) | ldub(Hp + 1, offnb);
+              pax = 0;
+              psh = 0;
+              wb = false;
+              hs1 = 0;
+              hs2 = 1;
             }
           }
           else if (t == 0 && r == 0) {
-            load_rot2<NV, MHD>(Sp, ncb, 1, -syb, off, pf);
-            if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp - sy, offb) | ldub(Hp, offb);
+            pax = 1;
+            psh = -syb;
+            wb = false;
+            hs1 = -sy;
+            hs2 = 0;
           }
           else if (t == 0 || t == 1) {
-            load_rot2<NV, MHD>(Sp, ncb, 1, syb, off, pf);
-            if constexpr (MHD) {
-              pfb = ldu(Sp + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
-              if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb - syb, off);
-            }
-            if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offb) | ldub(Hp + sy, offb);
+            pax = 1;
+            psh = syb;
+            bsh = -syb;
+            hs1 = 0;
+            hs2 = sy;
           }
           else {   // t == 2: the z task of this row
-            load_rot2<NV, MHD>(Sp, ncb, 2, szb, off, pf);
-            if constexpr (MHD) {
-              pfb = ldu(Sp + (long)rotvar<MHD>(2, qBN) * ncb - szb, off);
-              if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb - szb, off);
-            }
-            if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp, offb) | ldub(Hp + sz, offb);
+            pax = 2;
+            psh = szb;
+            bsh = -szb;
+            hs1 = 0;
+            hs2 = sz;
           }
+          const unsigned off = pin_v(nextcell ? offn_r : off_r), offb = pin_v(nextcell ? offnb_r : offb_r);
+          load_rot2<NV, MHD>(Sp, ncb, pax, psh, off, pf);
+          if constexpr (MHD) {
+            if (wb) {
+              pfb = ldu(Sp + (long)rotvar<MHD>(pax, qBN) * ncb + bsh, off);
+              if constexpr (EQ == EQGLM) pfs = ldu(Sp + (long)qSI * ncb + bsh, off);
+            }
+          }
+          if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp + hs1, offb) | ldub(Hp + hs2, offb);
         }
         FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 
