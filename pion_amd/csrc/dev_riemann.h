@@ -695,14 +695,15 @@ struct Flux {
   // order), the side K is selected, and only F_K, U_K, U*_K, U**_K are built:
   //     F = F_K + [region>=1] S_K (U*_K - U_K) + [region==2] S*_K (U**_K - U*_K),
   // which is the reference's expression regrouped (exact in real arithmetic, differs by rounding).
-  // Reciprocals are shared and a^2 = gamma p/rho is used where the strict form squares sqrt(a^2).
+  // Reciprocals are shared and a^2 = gamma p/rho is used where the strict form squares sqrt(a^2); reciprocals
+  // and roots are the forms with one refinement step (dev_eqns.h: frcp_r, sqrt_pos_r; 2^-47).
   static PDEV void hlld(const double *Pl, const double *Pr, const double g, double *out_flux, double *out_ustar,
                         double *out_pstar)
   {
     const double BX = 0.5 * (Pl[qBN] + Pr[qBN]);
     const double BX2 = BX * BX;
     // (pairs of reciprocals from one: 1/a = b/(ab), 1/b = a/(ab))
-    const double irlr = frcp(Pl[qRO] * Pr[qRO]);
+    const double irlr = frcp_r(Pl[qRO] * Pr[qRO]);
     const double irl = irlr * Pr[qRO], irr = irlr * Pl[qRO];
     // HLLD_signal_speeds with B_n := BX
     double cfm;
@@ -713,24 +714,24 @@ struct Flux {
       const double t2l = fmx(PION_MACHINEACCURACY, t1l * t1l - 4. * a2l * BX2 * irl);
       const double t2r = fmx(PION_MACHINEACCURACY, t1r * t1r - 4. * a2r * BX2 * irr);
       // max of the two fast speeds: the root is monotonic, so one outer root of the larger argument
-      cfm = sqrt_pos(fmx(t1l + sqrt_pos(t2l), t1r + sqrt_pos(t2r)) * 0.5);
+      cfm = sqrt_pos_r(fmx(t1l + sqrt_pos_r(t2l), t1r + sqrt_pos_r(t2r)) * 0.5);
     }
     const double SL = fmn(Pl[qVN], Pr[qVN]) - cfm, SR = fmx(Pl[qVN], Pr[qVN]) + cfm;
     const double sl_vl = SL - Pl[qVN], sr_vr = SR - Pr[qVN];
     const double ptl = E::mhd_Ptot(Pl), ptr = E::mhd_Ptot(Pr);
     const double rsl = Pl[qRO] * sl_vl, rsr = Pr[qRO] * sr_vr;
-    const double itemp = frcp(rsr - rsl);
+    const double itemp = frcp_r(rsr - rsl);
     const double SM = (rsr * Pr[qVN] - rsl * Pl[qVN] - ptr + ptl) * itemp;
     const double pts = (rsr * ptl - rsl * ptr + rsl * rsr * (Pr[qVN] - Pl[qVN])) * itemp;
     const double sl_sm = SL - SM, sr_sm = SR - SM;
-    const double islr_sm = frcp(sl_sm * sr_sm);
+    const double islr_sm = frcp_r(sl_sm * sr_sm);
     const double isl_sm = islr_sm * sr_sm, isr_sm = islr_sm * sl_sm;   // (one of them is reused for U*_K below)
     const double rosl = rsl * isl_sm, rosr = rsr * isr_sm;
     // tangential velocity and field behind the fast waves, both sides (the ** state needs both)
     double vys_l = Pl[qVT1], vzs_l = Pl[qVT2], bys_l = 0.0, bzs_l = 0.0;
     double vys_r = Pr[qVT1], vzs_r = Pr[qVT2], bys_r = 0.0, bzs_r = 0.0;
     {
-      const double den = frcp(rsl * sl_sm - BX2);
+      const double den = frcp_r(rsl * sl_sm - BX2);
       // a non-finite factor leaves the tangential state as it is: zero it (one select per factor)
       double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
       q1 = isfinite(q1) ? q1 : 0.0;
@@ -741,7 +742,7 @@ struct Flux {
       bzs_l = Pl[qBT2] * q2;
     }
     {
-      const double den = frcp(rsr * sr_sm - BX2);
+      const double den = frcp_r(rsr * sr_sm - BX2);
       double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
       q1 = isfinite(q1) ? q1 : 0.0;
       q2 = isfinite(q2) ? q2 : 0.0;
@@ -756,13 +757,13 @@ struct Flux {
     // and never uses it, here it would enter as 0 x NaN, so the argument of the root is kept positive
     // (v_max also drops a NaN).
     double sql, sqr, isql, isqr;
-    sqrt_rsqrt_pos(fmx(rosl, PION_TINYVALUE), sql, isql);
-    sqrt_rsqrt_pos(fmx(rosr, PION_TINYVALUE), sqr, isqr);
+    sqrt_rsqrt_pos_r(fmx(rosl, PION_TINYVALUE), sql, isql);
+    sqrt_rsqrt_pos_r(fmx(rosr, PION_TINYVALUE), sqr, isqr);
     const double aBX = fabs(BX);
     const double SsL = SM - aBX * isql, SsR = SM + aBX * isqr;
     // Alfven-averaged state
     const double sgn = (double)((BX > 0) - (BX < 0));
-    const double isum = frcp(sql + sqr);
+    const double isum = frcp_r(sql + sqr);
     const double vy_ss = (sql * vys_l + sqr * vys_r + (bys_r - bys_l) * sgn) * isum;
     const double vz_ss = (sql * vzs_l + sqr * vzs_r + (bzs_r - bzs_l) * sgn) * isum;
     const double by_ss = (sql * bys_r + sqr * bys_l + sql * sqr * (vys_r - vys_l) * sgn) * isum;
@@ -1469,10 +1470,27 @@ struct Flux {
       flux[uERG] -= ergvisc;
     }
     else {
+#ifdef PION_FAST_MATH
+      // fast speed of the mean state, written on the sums: the factors 1/2 are exact scalings and cancel
+      // (a^2 = g (pl + pr) / (rl + rr), B^2 / rho = (sum B)^2 / (2 sum rho)); one-step reciprocal and roots
+      double cfm;
+      {
+        const double ir = frcp_r(Pl[qRO] + Pr[qRO]);
+        const double bn = Pl[qBN] + Pr[qBN], b1 = Pl[qBT1] + Pr[qBT1], b2 = Pl[qBT2] + Pr[qBT2];
+        const double a2 = c.gamma * (Pl[qPG] + Pr[qPG]) * ir;
+        const double hbn2 = 0.5 * bn * bn * ir;
+        const double t1 = a2 + (hbn2 + 0.5 * (b1 * b1 + b2 * b2) * ir);
+        const double t2 = fmx(PION_MACHINEACCURACY, t1 * t1 - 4. * a2 * hbn2);
+        cfm = sqrt_pos_r((t1 + sqrt_pos_r(t2)) * 0.5);
+      }
+      const double cfeta = cfm * c.etav;
+      double prefactor = cfeta * pstar[qRO];
+#else
       double prefactor = E::cfast_components(0.5 * (Pl[qRO] + Pr[qRO]), 0.5 * (Pl[qPG] + Pr[qPG]),
                                              0.5 * (Pl[qBN] + Pr[qBN]), 0.5 * (Pl[qBT1] + Pr[qBT1]),
                                              0.5 * (Pl[qBT2] + Pr[qBT2]), c.gamma) *
                          c.etav * pstar[qRO];
+#endif
       double momvisc = prefactor * (Pr[qVN] - Pl[qVN]);
       double ergvisc = momvisc * pstar[qVN];
       flux[uMN] -= momvisc;
@@ -1483,7 +1501,7 @@ struct Flux {
       flux[uMT2] -= momvisc;
       ergvisc += momvisc * pstar[qVT2];
 #ifdef PION_FAST_MATH
-      prefactor *= frcp(pstar[qRO]);   // (= etav / (etav rho*); the same reciprocal UtoP forms)
+      prefactor = cfeta;   // (the reference's prefactor * etav / (etav rho*) = c_f eta without the round trip through rho*)
 #else
       prefactor *= c.etav / (c.etav * pstar[qRO]);
 #endif
