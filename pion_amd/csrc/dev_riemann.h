@@ -731,21 +731,20 @@ struct Flux {
     double vys_l = Pl[qVT1], vzs_l = Pl[qVT2], bys_l = 0.0, bzs_l = 0.0;
     double vys_r = Pr[qVT1], vzs_r = Pr[qVT2], bys_r = 0.0, bzs_r = 0.0;
     {
-      const double den = frcp_r(rsl * sl_sm - BX2);
-      // a non-finite factor leaves the tangential state as it is: zero it (one select per factor)
-      double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
-      q1 = isfinite(q1) ? q1 : 0.0;
-      q2 = isfinite(q2) ? q2 : 0.0;
+      // a vanishing denominator leaves the tangential state as it is: its (infinite) reciprocal becomes 0
+      // and with it both factors (the numerators are finite)
+      double den = frcp_r(rsl * sl_sm - BX2);
+      den = isfinite(den) ? den : 0.0;
+      const double q1 = (SM - Pl[qVN]) * den, q2 = (rsl * sl_vl - BX2) * den;
       vys_l = Pl[qVT1] - BX * Pl[qBT1] * q1;
       vzs_l = Pl[qVT2] - BX * Pl[qBT2] * q1;
       bys_l = Pl[qBT1] * q2;
       bzs_l = Pl[qBT2] * q2;
     }
     {
-      const double den = frcp_r(rsr * sr_sm - BX2);
-      double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
-      q1 = isfinite(q1) ? q1 : 0.0;
-      q2 = isfinite(q2) ? q2 : 0.0;
+      double den = frcp_r(rsr * sr_sm - BX2);
+      den = isfinite(den) ? den : 0.0;
+      const double q1 = (SM - Pr[qVN]) * den, q2 = (rsr * sr_vr - BX2) * den;
       vys_r = Pr[qVT1] - BX * Pr[qBT1] * q1;
       vzs_r = Pr[qVT2] - BX * Pr[qBT2] * q1;
       bys_r = Pr[qBT1] * q2;
@@ -762,7 +761,9 @@ struct Flux {
     const double aBX = fabs(BX);
     const double SsL = SM - aBX * isql, SsR = SM + aBX * isqr;
     // Alfven-averaged state
-    const double sgn = (double)((BX > 0) - (BX < 0));
+    // sign of B_n (+-1; the reference's 0 for B_n = 0 is not needed: the ** states, the only place it enters,
+    // are left out by w2 below when B_n = 0, and they stay finite either way)
+    const double sgn = __builtin_copysign(1.0, BX);
     const double isum = frcp_r(sql + sqr);
     const double vy_ss = (sql * vys_l + sqr * vys_r + (bys_r - bys_l) * sgn) * isum;
     const double vz_ss = (sql * vzs_l + sqr * vzs_r + (bzs_r - bzs_l) * sgn) * isum;

@@ -151,6 +151,23 @@ PDEV double cell_dt(const double *P, const int ndim, const double g, const doubl
     temp = sqrt(temp);
     temp += Eqn<EQEUL, 0>::chydro(p, g);
   }
+#ifdef PION_FAST_MATH
+  else if (ndim > 1) {
+    // fast build: the fast speed along the weakest-field axis needs rho, p, |B|^2 and the smallest of the three
+    // B_i^2 only -- no rotation of the state into that axis (the reference's sum of squares runs in the rotated
+    // order: last-bit differences), shared reciprocal, seeded roots
+    temp = fmx(fabs(p[2]), fabs(p[3]));
+    if (ndim > 2) temp = fmx(temp, fabs(p[4]));
+    const double bx2 = p[5] * p[5], by2 = p[6] * p[6], bz2 = p[7] * p[7];
+    const double bn2 = fmn(fmn(bx2, by2), bz2);
+    const double ir = frcp(p[0]);
+    const double a2 = g * p[1] * ir;
+    const double t1 = a2 + (bx2 + by2 + bz2) * ir;
+    const double t2 = fmx(PION_MACHINEACCURACY, t1 * t1 - 4. * a2 * bn2 * ir);
+    temp += sqrt_pos((t1 + sqrt_pos(t2)) * 0.5);
+    return dx * cfl * frcp(temp);
+  }
+#endif
   else {
     temp = fabs(p[2]);
     if (ndim > 1) temp = dmax(temp, fabs(p[3]));

@@ -112,17 +112,18 @@ PDEV void load_rot2(const char *Sb, const long ncb, const int ax, const long sh,
 // SetSlope x dx for one cell from its two neighbours (VectorOps.cpp:578-617, AvgFalle :37-59): the edge
 // states are q -+ hs / 2 (SetEdgeState :535-571).  Strict build: the reference's slope s = minmod(a/dx, b/dx)
 // (division form) times dx, so that q + hs * 0.5 is the reference's q + s * dx * 0.5 bit for bit.  Fast
-// build: minmod of the raw differences -- min(|a|, |b|) with the sign of a where a b > 1e-200 dx^2 -- no
-// division and no scaling by dx and back (<= 1 ulp from the reference form).
+// build: minmod of the raw differences as a median -- no division, no scaling by dx and back (<= 1 ulp from
+// the reference form), no product, compare and select.
 template <int NV>
 PDEV void hslope3(const double *qm, const double *q0, const double *qp, const double dx, const double thr, double *hs)
 {
 #pragma unroll
   for (int v = 0; v < NV; v++) {
 #ifdef PION_FAST_MATH
+    // minmod(a, b) = median(a, b, 0) = max(min(a, b), min(max(a, b), 0)): four min / max instructions
+    // (the reference's "a b <= 1e-200" also zeroes slopes below 1e-100 dx, which this form keeps)
     const double a = q0[v] - qm[v], b = qp[v] - q0[v];
-    const double m = __builtin_copysign(__builtin_fmin(__builtin_fabs(a), __builtin_fabs(b)), a);
-    hs[v] = (a * b <= thr) ? 0.0 : m;
+    hs[v] = fmx(fmn(a, b), fmn(fmx(a, b), 0.0));
 #else
     hs[v] = avg_falle((q0[v] - qm[v]) / dx, (qp[v] - q0[v]) / dx) * dx;
 #endif
