@@ -59,9 +59,83 @@ struct Flux {
   }
 
   // ------------------------------------------------------------------ Roe CV
+#ifdef PION_FAST_MATH
+  // Fast-build Roe solver in conserved variables: the strict function below (the reference's, Roe_Hydro_ConservedVar)
+  // with its arithmetic regrouped -- same wave decomposition, same entropy fix, results differ by rounding:
+  //   * sqrt(rho) and 1/sqrt(rho) come from one seeded root each, 1/rho is the square of the latter (enthalpies);
+  //     1/a_mean is the reciprocal root of a_mean^2;
+  //   * the left and right fluxes are written from the primitive states (the strict form recovers velocity and
+  //     pressure from the conserved vectors: a division and a subtraction of nearly equal numbers each);
+  //   * "equalD(ur, ul) ? 0 : ur - ul" is one comparison of |ur - ul| with 1e-12 (|ur| + |ul| + 1e-100);
+  //   * |lambda| after the H-correction is max(|lambda|, eta);
+  //   * the sound speed of the resolved state, which the FKJ98 viscosity asks for, is a_mean itself (out_cstar).
   static PDEV void roe_cv(const double *left, const double *right, const double g, const double hc_eta,
-                          double *out_pstar, double *out_flux)
+                          double *out_pstar, double *out_flux, double &out_cstar)
   {
+    double rl, irl, rr, irr;
+    sqrt_rsqrt_pos(left[qRO], rl, irl);
+    sqrt_rsqrt_pos(right[qRO], rr, irr);
+    const double igm1 = frcp(g - 1.0), ggm1 = g * igm1;   // (uniform, loop-invariant)
+    const double v2l = left[qVN] * left[qVN] + left[qVT1] * left[qVT1] + left[qVT2] * left[qVT2];
+    const double v2r = right[qVN] * right[qVN] + right[qVT1] * right[qVT1] + right[qVT2] * right[qVT2];
+    const double lH = 0.5 * v2l + ggm1 * left[qPG] * (irl * irl), rH = 0.5 * v2r + ggm1 * right[qPG] * (irr * irr);
+    const double denom = frcp(rl + rr);
+    const double wl = rl * denom, wr = rr * denom;
+    const double vn = wl * left[qVN] + wr * right[qVN], vt1 = wl * left[qVT1] + wr * right[qVT1],
+                 vt2 = wl * left[qVT2] + wr * right[qVT2], HH = wl * lH + wr * rH;
+    const double v2_mean = vn * vn + vt1 * vt1 + vt2 * vt2;
+    double a_mean, ia;
+    sqrt_rsqrt_pos((g - 1.0) * fmx(HH - 0.5 * v2_mean, 1.0e-12 * v2_mean), a_mean, ia);
+    const double ae0 = fmx(fabs(vn - a_mean), hc_eta), ae1 = fmx(fabs(vn), hc_eta), ae4 = fmx(fabs(vn + a_mean), hc_eta);
+    // conserved vectors, their jump, the two fluxes
+    double ul[5], ur[5], udiff[5];
+    ul[uRHO] = left[qRO];
+    ul[uMN] = left[qRO] * left[qVN];
+    ul[uMT1] = left[qRO] * left[qVT1];
+    ul[uMT2] = left[qRO] * left[qVT2];
+    ul[uERG] = left[qRO] * v2l * 0.5 + left[qPG] * igm1;
+    ur[uRHO] = right[qRO];
+    ur[uMN] = right[qRO] * right[qVN];
+    ur[uMT1] = right[qRO] * right[qVT1];
+    ur[uMT2] = right[qRO] * right[qVT2];
+    ur[uERG] = right[qRO] * v2r * 0.5 + right[qPG] * igm1;
+#pragma unroll
+    for (int v = 0; v < 5; v++) {
+      const double d = ur[v] - ul[v];
+      udiff[v] = (fabs(d) < PION_SMALLVALUE * (fabs(ur[v]) + fabs(ul[v]) + PION_TINYVALUE)) ? 0.0 : d;
+    }
+    double fsum[5];   // F(left) + F(right)
+    fsum[uRHO] = ul[uMN] + ur[uMN];
+    fsum[uMN] = (ul[uMN] * left[qVN] + left[qPG]) + (ur[uMN] * right[qVN] + right[qPG]);
+    fsum[uMT1] = ul[uMN] * left[qVT1] + ur[uMN] * right[qVT1];
+    fsum[uMT2] = ul[uMN] * left[qVT2] + ur[uMN] * right[qVT2];
+    fsum[uERG] = left[qVN] * (ul[uERG] + left[qPG]) + right[qVN] * (ur[uERG] + right[qPG]);
+    // wave strengths (Toro 11.68-11.70)
+    const double s2 = udiff[uMT1] - vt1 * udiff[uRHO], s3 = udiff[uMT2] - vt2 * udiff[uRHO];
+    const double u5bar = udiff[uERG] - s2 * vt1 - s3 * vt2;
+    const double s1 = (udiff[uRHO] * (HH - vn * vn) + vn * udiff[uMN] - u5bar) * (g - 1.0) * ia * ia;
+    const double s0 = 0.5 * (udiff[uRHO] * (vn + a_mean) - udiff[uMN] - a_mean * s1) * ia;
+    const double s4 = udiff[uRHO] - s0 - s1;
+    // sum over waves of strength |lambda| K (right eigenvectors, Toro 11.59)
+    const double w0 = s0 * ae0, w1 = s1 * ae1, w2 = s2 * ae1, w3 = s3 * ae1, w4 = s4 * ae4;
+    const double w014 = w0 + w1 + w4;
+    out_flux[uRHO] = 0.5 * (fsum[uRHO] - w014);
+    out_flux[uMN] = 0.5 * (fsum[uMN] - (w014 * vn + (w4 - w0) * a_mean));
+    out_flux[uMT1] = 0.5 * (fsum[uMT1] - (w014 * vt1 + w2));
+    out_flux[uMT2] = 0.5 * (fsum[uMT2] - (w014 * vt2 + w3));
+    out_flux[uERG] = 0.5 * (fsum[uERG] - ((w0 + w4) * HH + (w4 - w0) * vn * a_mean + w1 * 0.5 * v2_mean + w2 * vt1 + w3 * vt2));
+    out_pstar[qRO] = rl * rr;
+    out_pstar[qVN] = vn;
+    out_pstar[qVT1] = vt1;
+    out_pstar[qVT2] = vt2;
+    out_pstar[qPG] = out_pstar[qRO] * a_mean * a_mean / g;
+    out_cstar = a_mean;
+  }
+#else
+  static PDEV void roe_cv(const double *left, const double *right, const double g, const double hc_eta,
+                          double *out_pstar, double *out_flux, double &out_cstar)
+  {
+    out_cstar = -1.0;
     double meanp[5], ul[5], ur[5], eval[5], strength[5], udiff[5];
     double rl = psqrt(left[qRO]), rr = psqrt(right[qRO]), lH = E::Enthalpy(left, g), rH = E::Enthalpy(right, g),
            denom = prcp(rl + rr);
@@ -130,6 +204,7 @@ struct Flux {
     for (int v = 0; v < 5; v++) out_pstar[v] = meanp[v];
     out_pstar[qPG] = meanp[qRO] * a_mean * a_mean / g;
   }
+#endif
 
   // ------------------------------------------------------------------ Roe PV
   static PDEV void roe_pv(const double *l, const double *r, const double g, double *pstar)
@@ -1363,7 +1438,7 @@ struct Flux {
   // ------------------------------------------------------------------ dispatch
   // hydro: solver_eqn_hydro_adi.cpp:94-201; ideal MHD: solver_eqn_mhd_adi.cpp:102-200
   static PDEV void inviscid_ideal(const double *Pl, const double *Pr, double *flux, double *pstar, const FluxCtx &c,
-                                  const double hc_eta, const bool use_hll, int &err)
+                                  const double hc_eta, const bool use_hll, int &err, double &cstar)
   {
     const double g = c.gamma;
 #pragma unroll
@@ -1382,7 +1457,7 @@ struct Flux {
         jm_riemann(Pl, Pr, pstar, c, err);
         E::PtoFlux(pstar, flux, g);
       }
-      else if constexpr (SOLVER == FLUX_RSroe) roe_cv(Pl, Pr, g, hc_eta, pstar, flux);
+      else if constexpr (SOLVER == FLUX_RSroe) roe_cv(Pl, Pr, g, hc_eta, pstar, flux, cstar);
       else if constexpr (SOLVER == FLUX_RSroe_pv) {
         roe_pv(Pl, Pr, g, pstar);
         E::PtoFlux(pstar, flux, g);
@@ -1432,11 +1507,12 @@ struct Flux {
     }
   }
   // GLM wrapper: solver_eqn_mhd_adi.cpp:662-769
+  // (cstar: sound speed of the resolved state when the solver has it at hand, else < 0)
   static PDEV void inviscid(const double *Pl, const double *Pr, double *flux, double *pstar, const FluxCtx &c,
-                            const double hc_eta, const bool use_hll, int &err)
+                            const double hc_eta, const bool use_hll, int &err, double &cstar)
   {
     if constexpr (EQ != EQGLM) {
-      inviscid_ideal(Pl, Pr, flux, pstar, c, hc_eta, use_hll, err);
+      inviscid_ideal(Pl, Pr, flux, pstar, c, hc_eta, use_hll, err, cstar);
       return;
     }
     double left[NV], right[NV];
@@ -1449,16 +1525,17 @@ struct Flux {
     double bxstar = 0.5 * (left[qBN] + right[qBN] - (right[qSI] - left[qSI]));
     left[qSI] = right[qSI] = 0.0;
     left[qBN] = right[qBN] = bxstar;
-    inviscid_ideal(left, right, flux, pstar, c, hc_eta, use_hll, err);
+    inviscid_ideal(left, right, flux, pstar, c, hc_eta, use_hll, err, cstar);
     flux[uERG] += c.chyp * bxstar * psistar;
     flux[uBN] = c.chyp * psistar;
     flux[uPSI] = c.chyp * bxstar;
   }
 
-  static PDEV void av_falle(const double *Pl, const double *Pr, const double *pstar, double *flux, const FluxCtx &c)
+  static PDEV void av_falle(const double *Pl, const double *Pr, const double *pstar, double *flux, const FluxCtx &c,
+                            const double cstar)
   {
     if constexpr (EQ == EQEUL) {
-      double prefactor = E::chydro(pstar, c.gamma) * c.etav * pstar[qRO];
+      double prefactor = ((cstar >= 0.0) ? cstar : E::chydro(pstar, c.gamma)) * c.etav * pstar[qRO];
       double momvisc = prefactor * (Pr[qVN] - Pl[qVN]);
       double ergvisc = momvisc * pstar[qVN];
       flux[uMN] -= momvisc;
@@ -1520,8 +1597,9 @@ struct Flux {
   static PDEV void intercell_flux(const double *lp, const double *rp, double *f, double *pstar, const FluxCtx &c,
                                   const double hc_eta, const bool use_hll, int &err)
   {
-    inviscid(lp, rp, f, pstar, c, hc_eta, use_hll, err);
-    if (c.artvisc == AV_FKJ98_1D || c.artvisc == AV_HCORR_FKJ98) av_falle(lp, rp, pstar, f, c);
+    double cstar = -1.0;
+    inviscid(lp, rp, f, pstar, c, hc_eta, use_hll, err, cstar);
+    if (c.artvisc == AV_FKJ98_1D || c.artvisc == AV_HCORR_FKJ98) av_falle(lp, rp, pstar, f, c, cstar);
     if constexpr (NTR > 0) {
       if constexpr (SOLVER == FLUX_LF) {
         // get_LaxFriedrichs_flux sets the tracer flux first (solver_eqn_base.cpp:128-139);
