@@ -243,10 +243,22 @@ struct Flux {
   }
 
   // ------------------------------------------------------------------ FVS
-  static PDEV void fvs(const double *pl, const double *pr, double *flux, double *pstar, const double g)
+  static PDEV void fvs(const double *pl, const double *pr, double *flux, double *pstar, const double g, double &cstar)
   {
     double fpos[5], fneg[5];
+#ifdef PION_FAST_MATH
+    // fast build: sqrt(rho) and 1/sqrt(rho) from one seeded root per side (Roe weights below, 1/rho = its square for
+    // the sound speeds and the enthalpies), the sound speed with its reciprocal (Mach number) from a second one
+    double rl, irl, rr, irr, cl, icl, cr, icr;
+    sqrt_rsqrt_pos(pl[qRO], rl, irl);
+    sqrt_rsqrt_pos(pr[qRO], rr, irr);
+    const double iro_l = irl * irl, iro_r = irr * irr;
+    sqrt_rsqrt_pos(g * pl[qPG] * iro_l, cl, icl);
+    sqrt_rsqrt_pos(g * pr[qPG] * iro_r, cr, icr);
+    double Ml = pl[qVN] * icl, Mr = pr[qVN] * icr, f1 = 0.0, f2 = 0.0;
+#else
     double cl = E::chydro(pl, g), cr = E::chydro(pr, g), Ml = pl[qVN] / cl, Mr = pr[qVN] / cr, f1 = 0.0, f2 = 0.0;
+#endif
     if (Ml < -1.0) {
 #pragma unroll
       for (int v = 0; v < 5; v++) fpos[v] = 0.0;
@@ -285,6 +297,24 @@ struct Flux {
     }
 #pragma unroll
     for (int v = 0; v < 5; v++) flux[v] = fpos[v] + fneg[v];
+#ifdef PION_FAST_MATH
+    {
+      // Roe-average state for the viscosity: its sound speed is sqrt((g-1)(H - v^2/2)), handed over as cstar
+      // (the strict form turns it into a pressure, and the viscosity back into the sound speed)
+      const double den = frcp(rl + rr), wl = rl * den, wr = rr * den;
+      const double ggm1 = g * frcp(g - 1.0);   // (uniform)
+      const double Hl = 0.5 * (pl[qVN] * pl[qVN] + pl[qVT1] * pl[qVT1] + pl[qVT2] * pl[qVT2]) + ggm1 * pl[qPG] * iro_l;
+      const double Hr = 0.5 * (pr[qVN] * pr[qVN] + pr[qVT1] * pr[qVT1] + pr[qVT2] * pr[qVT2]) + ggm1 * pr[qPG] * iro_r;
+      pstar[qRO] = rl * rr;
+      pstar[qVN] = wl * pl[qVN] + wr * pr[qVN];
+      pstar[qVT1] = wl * pl[qVT1] + wr * pr[qVT1];
+      pstar[qVT2] = wl * pl[qVT2] + wr * pr[qVT2];
+      const double a2 = (g - 1.0) * ((wl * Hl + wr * Hr) - 0.5 * (pstar[qVN] * pstar[qVN] + pstar[qVT1] * pstar[qVT1] + pstar[qVT2] * pstar[qVT2]));
+      pstar[qPG] = pstar[qRO] * a2 / g;
+      cstar = (a2 > 0.0) ? sqrt_pos(a2) : -1.0;   // (< 0: the viscosity takes its own root of the pressure)
+      return;
+    }
+#endif
     double RoeAvg_rl = psqrt(pl[qRO]), RoeAvg_rr = psqrt(pr[qRO]), RoeAvg_denom = 1.0 / (RoeAvg_rl + RoeAvg_rr);
     pstar[qRO] = RoeAvg_rl * RoeAvg_rr;
     pstar[qVN] = (RoeAvg_rl * pl[qVN] + RoeAvg_rr * pr[qVN]) * RoeAvg_denom;
@@ -1452,7 +1482,7 @@ struct Flux {
       for (int v = 0; v < NV; v++) pstar[v] = 0.5 * (Pl[v] + Pr[v]);
     }
     else if constexpr (EQ == EQEUL) {
-      if constexpr (SOLVER == FLUX_FVS) fvs(Pl, Pr, flux, pstar, g);
+      if constexpr (SOLVER == FLUX_FVS) fvs(Pl, Pr, flux, pstar, g, cstar);
       else if constexpr (SOLVER == FLUX_RSlinear || SOLVER == FLUX_RSexact || SOLVER == FLUX_RShybrid) {
         jm_riemann(Pl, Pr, pstar, c, err);
         E::PtoFlux(pstar, flux, g);

@@ -123,6 +123,71 @@ PDEV void from_sweep(const int ax, const double *sw, double *lab)
   }
 }
 
+// CellTimeStep of a lab-frame state (solver_eqn_hydro_adi.cpp:460-502 / solver_eqn_mhd_adi.cpp:516-582);
+// the same operations as k_dt, used by the stage kernel to leave the next step's dt behind.
+template <int EQ>
+PDEV double cell_dt(const double *P, const int ndim, const double g, const double dx, const double cfl)
+{
+  double p[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) p[v] = (EQ != EQEUL || v < 5) ? P[v] : 0.0;
+  double temp;
+  if constexpr (EQ == EQEUL) {
+#ifdef PION_FAST_MATH
+    // fast build: seeded root (of |v|^2 + 1e-200: a cell at rest would otherwise ask for the root of zero),
+    // one reciprocal for dx / (|v| + c); multiply-adds written out (see below)
+    temp = PION_VERY_TINY_VALUE;
+    for (int v = 0; v < ndim; v++) temp = __builtin_fma(p[2 + v], p[2 + v], temp);
+    temp = sqrt_pos(temp) + sqrt_pos((g * p[1]) * frcp(p[0]));
+    return (dx * cfl) * frcp(temp);
+#else
+    temp = 0.0;
+    for (int v = 0; v < ndim; v++) temp += p[2 + v] * p[2 + v];
+    temp = sqrt(temp);
+    temp += Eqn<EQEUL, 0>::chydro(p, g);
+#endif
+  }
+#ifdef PION_FAST_MATH
+  else if (ndim > 1) {
+    // fast build: the fast speed along the weakest-field axis needs rho, p, |B|^2 and the smallest of the three
+    // B_i^2 only -- no rotation of the state into that axis (the reference's sum of squares runs in the rotated
+    // order: last-bit differences), shared reciprocal, seeded roots
+    // (multiply-adds written out: this function is compiled into k_dt and into the stage kernels, and a restart
+    // continues bit for bit only if both contract the same way)
+    temp = fmx(fabs(p[2]), fabs(p[3]));
+    if (ndim > 2) temp = fmx(temp, fabs(p[4]));
+    const double bx2 = p[5] * p[5], by2 = p[6] * p[6], bz2 = p[7] * p[7];
+    const double bn2 = fmn(fmn(bx2, by2), bz2);
+    const double ir = frcp(p[0]);
+    const double a2 = (g * p[1]) * ir;
+    const double t1 = __builtin_fma((bx2 + by2) + bz2, ir, a2);
+    const double t2 = fmx(PION_MACHINEACCURACY, __builtin_fma(t1, t1, -(4. * a2) * (bn2 * ir)));
+    temp += sqrt_pos((t1 + sqrt_pos(t2)) * 0.5);
+    return (dx * cfl) * frcp(temp);
+  }
+#endif
+  else {
+    temp = fabs(p[2]);
+    if (ndim > 1) temp = dmax(temp, fabs(p[3]));
+    if (ndim > 2) temp = dmax(temp, fabs(p[4]));
+    if (ndim == 1) temp += Eqn<EQMHD, 0>::cfast(p, g);
+    else {
+      int newdir = 0;
+      if (fabs(p[6]) < fabs(p[5])) {
+        newdir = 1;
+        if (fabs(p[7]) < fabs(p[6])) newdir = 2;
+      }
+      else if (fabs(p[7]) < fabs(p[5])) newdir = 2;
+      double u1[8];
+      to_sweep<8, true>(newdir, p, u1);
+      temp += Eqn<EQMHD, 0>::cfast(u1, g);
+    }
+  }
+  double t = dx / temp;
+  t *= cfl;
+  return t;
+}
+
 #if PION_EQSEL != 0
 // ---------------------------------------------------------------------------
 // select_Hcorr_eta (solver_eqn_base.cpp:608-678) for the interface (cl | cl+st) along ax.
@@ -977,32 +1042,9 @@ __global__ __launch_bounds__(256) void k_dt(const DtArgs a)
       double p[8];
       const int nvs = mhd ? 8 : 5;
       for (int v = 0; v < 8; v++) p[v] = (v < nvs) ? a.P[v * nc + c] : 0.0;
-      double temp;
-      if (!mhd) {
-        temp = 0.0;
-        for (int v = 0; v < a.g.ndim; v++) temp += p[2 + v] * p[2 + v];
-        temp = sqrt(temp);
-        temp += Eqn<EQEUL, 0>::chydro(p, g);
-      }
-      else {
-        temp = fabs(p[2]);
-        if (a.g.ndim > 1) temp = dmax(temp, fabs(p[3]));
-        if (a.g.ndim > 2) temp = dmax(temp, fabs(p[4]));
-        if (a.g.ndim == 1) temp += Eqn<EQMHD, 0>::cfast(p, g);
-        else {
-          int newdir = 0;
-          if (fabs(p[6]) < fabs(p[5])) {
-            newdir = 1;
-            if (fabs(p[7]) < fabs(p[6])) newdir = 2;
-          }
-          else if (fabs(p[7]) < fabs(p[5])) newdir = 2;
-          double u1[8];
-          to_sweep<8, true>(newdir, p, u1);  // eqns_mhd_ideal::rotate(u1,XX,newdir)
-          temp += Eqn<EQMHD, 0>::cfast(u1, g);
-        }
-      }
-      double t = a.g.dx / temp;
-      t *= a.cfl;
+      // (the function the stage kernel's fused reduction calls: a restart, which comes through here, continues bit
+      // for bit)
+      const double t = mhd ? cell_dt<EQMHD>(p, a.g.ndim, g, a.g.dx, a.cfl) : cell_dt<EQEUL>(p, a.g.ndim, g, a.g.dx, a.cfl);
       if (!(t > 0.0)) err |= ERR_BAD_DT;
       tdyn = (t < tdyn) ? t : tdyn;
     }

@@ -136,60 +136,6 @@ PDEV void cell_update_store(const StageArgs &a, const long c, const double *P0, 
   }
 }
 
-// CellTimeStep of a lab-frame state (solver_eqn_hydro_adi.cpp:460-502 / solver_eqn_mhd_adi.cpp:516-582);
-// the same operations as k_dt, used by the stage kernel to leave the next step's dt behind.
-template <int EQ>
-PDEV double cell_dt(const double *P, const int ndim, const double g, const double dx, const double cfl)
-{
-  double p[8];
-#pragma unroll
-  for (int v = 0; v < 8; v++) p[v] = (EQ != EQEUL || v < 5) ? P[v] : 0.0;
-  double temp;
-  if constexpr (EQ == EQEUL) {
-    temp = 0.0;
-    for (int v = 0; v < ndim; v++) temp += p[2 + v] * p[2 + v];
-    temp = sqrt(temp);
-    temp += Eqn<EQEUL, 0>::chydro(p, g);
-  }
-#ifdef PION_FAST_MATH
-  else if (ndim > 1) {
-    // fast build: the fast speed along the weakest-field axis needs rho, p, |B|^2 and the smallest of the three
-    // B_i^2 only -- no rotation of the state into that axis (the reference's sum of squares runs in the rotated
-    // order: last-bit differences), shared reciprocal, seeded roots
-    temp = fmx(fabs(p[2]), fabs(p[3]));
-    if (ndim > 2) temp = fmx(temp, fabs(p[4]));
-    const double bx2 = p[5] * p[5], by2 = p[6] * p[6], bz2 = p[7] * p[7];
-    const double bn2 = fmn(fmn(bx2, by2), bz2);
-    const double ir = frcp(p[0]);
-    const double a2 = g * p[1] * ir;
-    const double t1 = a2 + (bx2 + by2 + bz2) * ir;
-    const double t2 = fmx(PION_MACHINEACCURACY, t1 * t1 - 4. * a2 * bn2 * ir);
-    temp += sqrt_pos((t1 + sqrt_pos(t2)) * 0.5);
-    return dx * cfl * frcp(temp);
-  }
-#endif
-  else {
-    temp = fabs(p[2]);
-    if (ndim > 1) temp = dmax(temp, fabs(p[3]));
-    if (ndim > 2) temp = dmax(temp, fabs(p[4]));
-    if (ndim == 1) temp += Eqn<EQMHD, 0>::cfast(p, g);
-    else {
-      int newdir = 0;
-      if (fabs(p[6]) < fabs(p[5])) {
-        newdir = 1;
-        if (fabs(p[7]) < fabs(p[6])) newdir = 2;
-      }
-      else if (fabs(p[7]) < fabs(p[5])) newdir = 2;
-      double u1[8];
-      to_sweep<8, true>(newdir, p, u1);
-      temp += Eqn<EQMHD, 0>::cfast(u1, g);
-    }
-  }
-  double t = dx / temp;
-  t *= cfl;
-  return t;
-}
-
 PDEV double wave_min64(double v)
 {
 #pragma unroll

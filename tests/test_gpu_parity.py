@@ -284,10 +284,9 @@ def test_fused_dt_equals_dt_kernel(case, strict):
             fused = g.calc_dt()
             g.device_ptr(0)          # invalidates the cached minima -> next call runs k_dt
             kern = g.calc_dt()
-            if strict:
-                assert fused == kern, (fused, kern)
-            else:
-                assert np.allclose(fused, kern, rtol=1e-13, atol=0.0), (fused, kern)
+            # both builds: k_dt and the fused reduction call the same function (cell_dt, kernels_fp.hip), whose
+            # fast-build form spells its multiply-adds out -- a restart goes through k_dt and must continue bit for bit
+            assert fused == kern, (fused, kern)
 
 
 @pytest.mark.parametrize("strict", [1, 0])
