@@ -175,7 +175,8 @@ int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate);
 
 /* mp_only_cooling look-up tables (microphysics/mp_only_cooling.cpp:528-579):
  * nT temperatures, 5 value tables and 5 slope tables in the order
- * rrhp, C_rrh, C_ffhe, C_fbdn, C_cie. */
+ * rrhp, C_rrh, C_ffhe, C_fbdn, C_cie.  2 <= nT <= 256 (the reference builds 200 points; the cooling kernel
+ * keeps the tables in LDS), else PION_GPU_EINVAL. */
 int pion_gpu_set_cooling_tables(void *handle, int nT, const double *T,
                                 const double *tabs, const double *slopes);
 

@@ -605,6 +605,21 @@ __global__ __launch_bounds__(256) void k_cooling_dE(const StageArgs a)
   const unsigned gx = (a.g.ng[0] + 63) / 64, gy = (a.g.ng[1] + 3) / 4;
   const unsigned np1 = (unsigned)(a.kz1 - a.kz0), np2 = (a.kz3 > a.kz2) ? (unsigned)(a.kz3 - a.kz2) : 0u;
   const unsigned ntile = gx * gy * (np1 + np2);
+  // The rate tables (temperature grid, five rates and their slopes: 11 NT doubles, 17.6 KB at NT = 200) go to LDS
+  // first: an Edot is a bisection (8 dependent look-ups) plus 10 table reads, a Cash-Karp step six of those, and a
+  // thread is bound by the latency of that chain -- LDS answers several times sooner than the L1 / L2 path.
+  __shared__ double ctab[11 * PION_COOL_NT_MAX];
+  const int NT = a.cool.NT;
+  for (int i = threadIdx.x; i < NT; i += 256) ctab[i] = a.cool.T[i];
+  for (int i = threadIdx.x; i < 5 * NT; i += 256) {
+    ctab[NT + i] = a.cool.tab[i];
+    ctab[6 * NT + i] = a.cool.slope[i];
+  }
+  __syncthreads();
+  CoolDev cool = a.cool;
+  cool.T = ctab;
+  cool.tab = ctab + NT;
+  cool.slope = ctab + 6 * NT;
   const unsigned t = (unsigned)xcd_tile(blockIdx.x, ntile);
   if (t >= ntile) return;
   const int ix = (int)((t % gx) * 64 + (threadIdx.x & 63));
@@ -621,7 +636,7 @@ __global__ __launch_bounds__(256) void k_cooling_dE(const StageArgs a)
     double P0[NV], pn[NV], ui[NV], uf[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) pn[v] = P0[v] = a.Pc[v * nc + c];
-    pn[qPG] = Cooling::time_update(a.cool, P0[qRO], P0[qPG], a.dt, g, err);
+    pn[qPG] = Cooling::time_update(cool, P0[qRO], P0[qPG], a.dt, g, err);
     E::PtoU(P0, ui, g);
     E::PtoU(pn, uf, g);
     dE = uf[uERG] - ui[uERG];

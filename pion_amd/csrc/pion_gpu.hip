@@ -807,7 +807,11 @@ int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
 int pion_gpu_set_cooling_tables(void *handle, int nT, const double *T, const double *tabs, const double *slopes)
 {
   Handle *h = use(handle);
-  if (nT < 2) return PION_GPU_EINVAL;
+  if (nT < 2 || nT > PION_COOL_NT_MAX) {
+    // (k_cooling_dE keeps the tables in LDS: 11 x PION_COOL_NT_MAX doubles; mp_only_cooling builds 200 points)
+    h->err = "cooling tables: 2 <= nT <= 256 required";
+    return PION_GPU_EINVAL;
+  }
   hipFree(h->dcoolT);
   hipFree(h->dcooltab);
   hipFree(h->dcoolslope);

@@ -67,3 +67,14 @@ def test_wind3d_steps(strict):
             else:
                 scale = np.abs(b).reshape(cfg.nvar, -1).max(axis=1).reshape(-1, 1, 1, 1)
                 assert np.max(np.abs(a - b) / scale) <= 1e-10
+
+
+def test_cooling_tables_size_is_checked():
+    """k_cooling_dE holds the tables in LDS (11 x 256 doubles): larger tables are refused, not truncated"""
+    from pion_amd import lib
+    cfg, P, (idx, st), dtl = problems.wind3d(8, strict_fp=1)
+    with lib.GpuSim(cfg, 0) as g:
+        n = 300
+        T = np.logspace(1, 9, n)
+        with pytest.raises(Exception):
+            g.set_cooling_tables(T, np.ones((5, n)), np.zeros((5, n)))

@@ -87,3 +87,26 @@ def test_strict_build_bitexact_blast_64cubed():
     """the same problem, parity build: bit for bit after three steps (oracle cost ~2 s/step)"""
     cfg, P = problems.mhd_blast_generic([64, 64, 64], abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
     run_pair(cfg, P, 3)
+
+
+@pytest.mark.parametrize("strict", [1, 0])
+@pytest.mark.parametrize("case", ["hd_roe", "hd_fvs_tr", "glm_hlld"])
+def test_rows_per_wavefront_do_not_change_the_result(case, strict, monkeypatch):
+    """k_stage_rows2 picks its rows per wavefront per instance (Euler: for three workgroups' LDS per CU; MHD: for
+    two; PION_ROWS / PION_ROWS1 override).  The choice only moves work between wavefronts: every interface flux
+    is the same function of the same states, so the result is the same bit for bit -- in the fast build too."""
+    cfg, P = _case(case, [70, 14, 12], strict)
+    out = {}
+    for rows in (None, "1", "3"):
+        if rows is None:
+            monkeypatch.delenv("PION_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("PION_ROWS", rows)
+        with _gpu(cfg) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            sc.time_int(3)
+            out[rows] = (g.download(0), sc.simtime)
+    for rows in ("1", "3"):
+        assert out[rows][1] == out[None][1]
+        assert np.array_equal(out[rows][0], out[None][0]), rows
