@@ -123,6 +123,8 @@ PDEV void from_sweep(const int ax, const double *sw, double *lab)
   }
 }
 
+#include "dev_addr.h"
+
 // CellTimeStep of a lab-frame state (solver_eqn_hydro_adi.cpp:460-502 / solver_eqn_mhd_adi.cpp:516-582);
 // the same operations as k_dt, used by the stage kernel to leave the next step's dt behind.
 template <int EQ>
@@ -893,28 +895,44 @@ __global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
   const long sy = a.g.sy, sz = a.g.sz;
   const double dx = a.g.dx;
   const double *P = a.S + 1 * nc;
-  long c = (long)ix + sy * iy + sz * k0;
   const bool xl = ix > 0, xh = ix < a.g.nga[0] - 1, yl = iy > 0, yh = iy < a.g.nga[1] - 1;
-  double p0 = P[c], pm = (k0 > 0) ? P[c - sz] : p0;
-  for (int k = k0; k < k1; k++, c += sz) {
+  // Addressing as in k_stage_rows2: uniform base (the pressure array, moved by the scalar unit from plane to
+  // plane) + one 32-bit byte offset per lane and neighbour.  A cell on a face of the array takes itself for the
+  // missing neighbour (the reference's one-sided difference): its neighbour offset IS its own offset, so the
+  // loop has neither selects nor branches for the faces.  (launch_prepass uses this kernel only while 8 ncell
+  // fits 32 bits.)
+  const unsigned cb = (unsigned)((long)ix + sy * iy);   // cell inside a plane
+  const unsigned o0 = cb * 8u;
+  const unsigned oxm = xl ? o0 - 8u : o0, oxp = xh ? o0 + 8u : o0;
+  const unsigned oym = yl ? o0 - (unsigned)sy * 8u : o0, oyp = yh ? o0 + (unsigned)sy * 8u : o0;
+  const char *Pk = reinterpret_cast<const char *>(P) + sz * 8 * k0;   // plane k (uniform)
+  char *Hk = reinterpret_cast<char *>(a.hllflag) + sz * k0;
+  double p0 = ldu(Pk, o0), pm = (k0 > 0) ? ldu(Pk - sz * 8, o0) : p0;
+  for (int k = k0; k < k1; k++, Pk += sz * 8, Hk += sz) {
     const bool zl = k > 0, zh = k < a.g.nga[2] - 1;
-    const double pz = zh ? P[c + sz] : p0;
+    const unsigned q0 = pin_v(o0), qxm = pin_v(oxm), qxp = pin_v(oxp), qym = pin_v(oym), qyp = pin_v(oyp);
+    const double pz = zh ? ldu(Pk + sz * 8, q0) : p0;
     double pn3[3], pp3[3];
-    pn3[0] = xl ? P[c - 1] : p0;
-    pp3[0] = xh ? P[c + 1] : p0;
-    pn3[1] = yl ? P[c - sy] : p0;
-    pp3[1] = yh ? P[c + sy] : p0;
+    pn3[0] = ldu(Pk, qxm);
+    pp3[0] = ldu(Pk, qxp);
+    pn3[1] = ldu(Pk, qym);
+    pp3[1] = ldu(Pk, qyp);
     pn3[2] = zl ? pm : p0;
     pp3[2] = pz;
+    // |pp - pn| <= 1.6 min(pp, pn), as two comparisons (a NaN fails both and counts as steep, as before)
     bool steep = false;
 #pragma unroll
-    for (int v = 0; v < 3; v++)
-      if (!(fabs(pp3[v] - pn3[v]) <= 1.6 * fmin(pp3[v], pn3[v]))) steep = true;   // (NaN counts as steep)
+    for (int v = 0; v < 3; v++) {
+      const double d = fabs(pp3[v] - pn3[v]);
+      if (!(d <= 1.6 * pp3[v]) || !(d <= 1.6 * pn3[v])) steep = true;
+    }
     uint8_t flag = 0;
     if (steep) {
       double gradp = 0.0, divv = 0.0;
       for (int v = 0; v < 3; v++) gradp += fabs(pp3[v] - pn3[v]) / fmin(pp3[v], pn3[v]);   // GradZone
       if (gradp > 5.) {
+        // (rare: the cell's index is only formed here)
+        const long c = (long)cb + sz * ((long)k + opaque_zero());
         const bool lo[3] = {xl, yl, zl}, hi[3] = {xh, yh, zh};
         for (int v = 0; v < 3; v++) {
           const long st = (v == 0) ? 1 : ((v == 1) ? sy : sz);
@@ -925,7 +943,7 @@ __global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
         flag = (divv < 0.) ? 1 : 0;
       }
     }
-    a.hllflag[c] = flag;
+    stub(Hk, pin_v(cb), flag);
     pm = p0;
     p0 = pz;
   }
@@ -1015,7 +1033,8 @@ int launch_prepass(const PrepassArgs &a, hipStream_t s)
     const long plane = (long)a.g.nga[0] * a.g.nga[1];
     const unsigned npl = (unsigned)((a.c1 - a.c0) / plane) + ((a.c3 > a.c2) ? (unsigned)((a.c3 - a.c2) / plane) : 0u);
     const unsigned ntile = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * npl;
-    if (a.g.ndim == 3 && a.g.cyl == 0 && !a.divv && !a.gradp && a.c3 <= a.c2 && npl >= PION_PREPASS_ZC) {
+    if (a.g.ndim == 3 && a.g.cyl == 0 && !a.divv && !a.gradp && a.c3 <= a.c2 && npl >= PION_PREPASS_ZC
+        && a.g.ncell * 8L < (1L << 32)) {
       const unsigned nch = (npl + PION_PREPASS_ZC - 1) / PION_PREPASS_ZC;
       const unsigned nt = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * nch;
       hipLaunchKernelGGL(k_prepass_hlld_march, dim3(((nt + 7) / 8) * 8), dim3(256), 0, s, a);

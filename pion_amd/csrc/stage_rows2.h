@@ -28,33 +28,6 @@
 #define PION_ROWS2_NT 1   // non-temporal stores of the new state / loads of the once-read start-of-step state (25.35-25.43 vs 25.5-25.6 ms/step; 2 = also the z planes: 25.52)
 #endif
 
-// Addressing: every global access of the kernel is "uniform base + 32-bit per-lane byte offset"
-// (global_load ... v_off, s[base:base+1]): the variable, the neighbour shift along y / z and the array are
-// folded into the scalar base, the x neighbours into the instruction's immediate offset, and the one
-// per-lane quantity -- the cell -- is a single VGPR per row.  (With 64-bit per-lane addresses the compiler
-// hoists one VGPR pair per load site out of the task loop: ~80 registers, which do not exist here.)
-// Needs 8 * ncell < 2^32 (pion_gpu_create picks the cell-per-thread kernel otherwise; 512^3 with ghosts is 1.1e9).
-// (readfirstlane keeps the optimiser from re-associating base + offset into per-lane 64-bit arithmetic; on a
-// value that already lives in SGPRs it costs nothing.  The access is made through an address_space(1)
-// pointer so that it stays a global_ instruction after the integer round trip.)
-PDEV unsigned long long uni(const void *p)
-{
-  const unsigned long long x = reinterpret_cast<unsigned long long>(p);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-PDEV double ldu(const char *ubase, const unsigned off)
-{
-  typedef const __attribute__((address_space(1))) char *gc;
-  typedef const __attribute__((address_space(1))) double *gp;
-  return *(gp)((gc)uni(ubase) + off);
-}
-PDEV unsigned ldub(const char *ubase, const unsigned off)
-{
-  typedef const __attribute__((address_space(1))) unsigned char *gp;
-  return *((gp)uni(ubase) + off);
-}
 PDEV void stu(char *ubase, const unsigned off, const double x)
 {
   typedef __attribute__((address_space(1))) char *gc;
@@ -75,25 +48,6 @@ PDEV double ldu_once(const char *ubase, const unsigned off)
 #else
   return *(gp)((gc)uni(ubase) + off);
 #endif
-}
-// an SGPR zero the optimiser cannot see through: added to an array base inside a task it keeps the
-// (loop-invariant) scalar address arithmetic of that task from being hoisted out of the row / plane loops,
-// where its ~70 base pairs would have to be spilled (SGPR spills cost VALU lane moves)
-PDEV unsigned opaque_zero()
-{
-  unsigned z;
-  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-  return z;
-}
-// The per-lane offset as the block that uses it sees it.  Instruction selection works one basic block at a time
-// and folds "uniform base + zext(32-bit lane offset)" into the scalar-base form of a global access
-// (global_load v, v_off, s[base:base+1]) only when the zero-extension is in the block of the access; the
-// optimiser otherwise keeps ONE 64-bit copy of the offset per row (hoisted) and every access pays a 64-bit
-// VALU add (v_lshl_add_u64) for its address.  An empty volatile asm re-defines the offset inside the block.
-PDEV unsigned pin_v(unsigned x)
-{
-  asm volatile("" : "+v"(x));
-  return x;
 }
 // sweep-frame state of the cell at uniform byte shift `sh` from the lane's cell
 template <int NV, bool MHD>
