@@ -880,18 +880,24 @@ __global__ __launch_bounds__(256) void k_prepass_hlld(const PrepassArgs a)
 __global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
 {
   const long nc = a.g.ncell;
-  const unsigned gx = (a.g.nga[0] + 63) / 64, gy = (a.g.nga[1] + 3) / 4;
+  // x: 62 cells per wavefront; lanes 0 and 63 only supply their neighbours' x-1 / x+1 pressure through wavefront
+  // shuffles (no loads for the x neighbours)
+  const unsigned gx = (a.g.nga[0] + 61) / 62, gy = (a.g.nga[1] + 3) / 4;
   const long plane = (long)a.g.nga[0] * a.g.nga[1];
   const int kz0 = (int)(a.c0 / plane), kz1 = (int)(a.c1 / plane);
   const unsigned nch = (unsigned)((kz1 - kz0 + PION_PREPASS_ZC - 1) / PION_PREPASS_ZC);
   const unsigned ntile = gx * gy * nch;
   const unsigned t = (unsigned)xcd_tile(blockIdx.x, ntile);
   if (t >= ntile) return;
-  const int ix = (int)((t % gx) * 64 + (threadIdx.x & 63));
+  const int lane = (int)(threadIdx.x & 63);
+  int ix = (int)((t % gx) * 62) - 1 + lane;
+  const bool xwriter = (lane >= 1 && lane <= 62 && ix < a.g.nga[0]);
+  if (ix < 0) ix = 0;
+  if (ix > a.g.nga[0] - 1) ix = a.g.nga[0] - 1;
   const int iy = (int)(((t / gx) % gy) * 4 + (threadIdx.x >> 6));
   const int k0 = kz0 + (int)(t / (gx * gy)) * PION_PREPASS_ZC;
   const int k1 = (k0 + PION_PREPASS_ZC < kz1) ? k0 + PION_PREPASS_ZC : kz1;
-  if (ix >= a.g.nga[0] || iy >= a.g.nga[1]) return;
+  if (iy >= a.g.nga[1]) return;   // (whole wavefront: iy is uniform)
   const long sy = a.g.sy, sz = a.g.sz;
   const double dx = a.g.dx;
   const double *P = a.S + 1 * nc;
@@ -903,18 +909,20 @@ __global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
   // fits 32 bits.)
   const unsigned cb = (unsigned)((long)ix + sy * iy);   // cell inside a plane
   const unsigned o0 = cb * 8u;
-  const unsigned oxm = xl ? o0 - 8u : o0, oxp = xh ? o0 + 8u : o0;
   const unsigned oym = yl ? o0 - (unsigned)sy * 8u : o0, oyp = yh ? o0 + (unsigned)sy * 8u : o0;
   const char *Pk = reinterpret_cast<const char *>(P) + sz * 8 * k0;   // plane k (uniform)
   char *Hk = reinterpret_cast<char *>(a.hllflag) + sz * k0;
   double p0 = ldu(Pk, o0), pm = (k0 > 0) ? ldu(Pk - sz * 8, o0) : p0;
   for (int k = k0; k < k1; k++, Pk += sz * 8, Hk += sz) {
     const bool zl = k > 0, zh = k < a.g.nga[2] - 1;
-    const unsigned q0 = pin_v(o0), qxm = pin_v(oxm), qxp = pin_v(oxp), qym = pin_v(oym), qyp = pin_v(oyp);
+    const unsigned q0 = pin_v(o0), qym = pin_v(oym), qyp = pin_v(oyp);
     const double pz = zh ? ldu(Pk + sz * 8, q0) : p0;
     double pn3[3], pp3[3];
-    pn3[0] = ldu(Pk, qxm);
-    pp3[0] = ldu(Pk, qxp);
+    // x neighbours from the neighbouring lanes (a cell on an x face of the array takes itself; the halo lanes'
+    // own results are not written)
+    const double pl_ = __shfl_up(p0, 1, 64), pr_ = __shfl_down(p0, 1, 64);
+    pn3[0] = xl ? pl_ : p0;
+    pp3[0] = xh ? pr_ : p0;
     pn3[1] = ldu(Pk, qym);
     pp3[1] = ldu(Pk, qyp);
     pn3[2] = zl ? pm : p0;
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
         flag = (divv < 0.) ? 1 : 0;
       }
     }
-    stub(Hk, pin_v(cb), flag);
+    if (xwriter) stub(Hk, pin_v(cb), flag);
     pm = p0;
     p0 = pz;
   }
@@ -1036,7 +1044,7 @@ int launch_prepass(const PrepassArgs &a, hipStream_t s)
     if (a.g.ndim == 3 && a.g.cyl == 0 && !a.divv && !a.gradp && a.c3 <= a.c2 && npl >= PION_PREPASS_ZC
         && a.g.ncell * 8L < (1L << 32)) {
       const unsigned nch = (npl + PION_PREPASS_ZC - 1) / PION_PREPASS_ZC;
-      const unsigned nt = (unsigned)((a.g.nga[0] + 63) / 64) * ((a.g.nga[1] + 3) / 4) * nch;
+      const unsigned nt = (unsigned)((a.g.nga[0] + 61) / 62) * ((a.g.nga[1] + 3) / 4) * nch;   // 62 cells per wavefront along x
       hipLaunchKernelGGL(k_prepass_hlld_march, dim3(((nt + 7) / 8) * 8), dim3(256), 0, s, a);
     }
     else hipLaunchKernelGGL(k_prepass_hlld, dim3(((ntile + 7) / 8) * 8), dim3(256), 0, s, a);
