@@ -1,7 +1,8 @@
-// stage_rows2.h -- k_stage_rows2: the 3-D production stage kernel, two wavefronts per SIMD.
+// stage_rows2.h -- k_stage_rows2: the 3-D production stage kernel, two wavefronts per SIMD (MHD) or three (Euler).
 //
-// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after stage_march.h and stage_rows.h,
-// whose helpers load_rot / slope3 / apply_axis / cell_update_store / cell_dt / rows_tiling it reuses).
+// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after dev_addr.h, stage_march.h and stage_rows.h,
+// whose helpers uni / ldu / pin_v / opaque_zero, apply_axis / cell_update, rows_tiling it uses; cell_dt is
+// kernels_fp.hip's).
 //
 // Same decomposition as round 1's k_stage_rows (removed; one wavefront per x-pencil of 64 lanes owning R consecutive
 // y-rows, marching along z; x fluxes shared by wavefront shuffles, the y flux and the next row's y slope
@@ -19,7 +20,9 @@
 //     current plane is rebuilt from plane k-1 (R = 4 rows at nvar 9: 3.25 instead of 3.5 Riemann solves per
 //     cell, one more read of each plane, which comes from L2 / the Infinity Cache);
 //   * the first-order stage reads the start-of-step state from the stencil array (they are the same
-//     array in that stage), the cooling source arrives as one double per cell from k_cooling.
+//     array in that stage), the cooling source arrives as one double per cell from k_cooling;
+//   * the Euler instances need ~160 registers: the host picks their rows per wavefront so that THREE workgroups'
+//     LDS fits a CU (stage_rows2_rows), and three wavefronts per SIMD run.
 // The arithmetic and its order are the reference's (the strict build stays bit-identical to the oracle).
 #ifndef PION_STAGE_ROWS2_H
 #define PION_STAGE_ROWS2_H
