@@ -283,6 +283,9 @@ int pion_gpu_interface_flux(void *handle, int n, int axis, double dt, const doub
 int pion_gpu_cooling_update(void *handle, int n, double dt, const double *P_in, double *P_out);
 /* mp_only_cooling::Edot (:491-521) for n (rho,T) pairs */
 int pion_gpu_cooling_edot(void *handle, int n, const double *rho, const double *T, double *edot);
+/* mp_only_cooling::timescales(P, gamma, tc=true, ...) (:333-368) for n independent cells: P_in n*nvar,
+ * t_cool n doubles (1e99 below 1.1 MinT_allowed) */
+int pion_gpu_cooling_timescale(void *handle, int n, const double *P_in, double *t_cool);
 
 /* last kernel timings, milliseconds, measured with HIP events on the handle's stream:
  * out[0]=stage kernel, out[1]=prepass, out[2]=bc fill, out[3]=dt reduction (mean per launch);

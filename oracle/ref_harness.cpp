@@ -311,6 +311,12 @@ class HarnessODE : public Integrator_Base {
   int D_rate(const int, const double *, double *) { return DONT_CALL_ME; }
 };
 
+// oracle/ref_cooling.cpp: the reference's own mp_only_cooling object (its three spline-backed rate
+// curves are test doubles fed by the test); available once the test has supplied the curves
+extern "C" int ref_cooling_have_curves();
+extern "C" microphysics_base *ref_cooling_new_mp(int nv, int ntr, const std::string *tr, which_physics *ep,
+                                                 rad_sources *rs);
+
 // ---------------------------------------------------------------------------
 struct RefSim : public periodic_bc,
                 public oneway_out_bc,  // derives from outflow_bc
@@ -325,7 +331,8 @@ struct RefSim : public periodic_bc,
   SimParams par;
   HarnessGrid *grid;
   FV_solver_base *solver;
-  HarnessMP *hmp;
+  microphysics_base *hmp;
+  bool real_mp;  // MP is the reference's mp_only_cooling (else the HarnessMP stand-in)
   std::string trnames[PION_MAX_NVAR];
   cell *scratchL, *scratchR;
 
@@ -346,7 +353,7 @@ struct RefSim : public periodic_bc,
     }
   }
 
-  RefSim(const pion_gpu_config &c) : cfg(c), grid(0), solver(0), hmp(0)
+  RefSim(const pion_gpu_config &c) : cfg(c), grid(0), solver(0), hmp(0), real_mp(false)
   {
     par.gridType = 1;
     par.eqntype = c.eqntype;
@@ -398,7 +405,12 @@ struct RefSim : public periodic_bc,
     MP = 0;
     if (c.cooling != 0) {
       for (int t = 0; t < c.ntracer; t++) trnames[t] = "colour";
-      hmp = new HarnessMP(c.nvar, c.ntracer, trnames, &par.EP, &par.RS);
+      if (ref_cooling_have_curves()) {
+        hmp = ref_cooling_new_mp(c.nvar, c.ntracer, trnames, &par.EP, &par.RS);
+        real_mp = true;
+      }
+      else
+        hmp = new HarnessMP(c.nvar, c.ntracer, trnames, &par.EP, &par.RS);
       MP = hmp;
     }
     // setup_fixed_grid::set_equations (grid/setup_fixed_grid.cpp:1067-1191), Cartesian
@@ -646,11 +658,45 @@ struct RefSim : public periodic_bc,
         for (int v = 0; v < par.nvar; v++) c->P[v] = c->Ph[v];
     } while ((c = grid->NextPt_All(c)) != 0);
   }
-  // first_order_update / second_order_update (:151-250) without microphysics dU
+  // time_integrator::calc_noRT_microphysics_dU (sim_control/time_integrator.cpp:438-489): every call
+  // goes to the reference's MP and solver objects
+  int calc_noRT_microphysics_dU(const double delt)
+  {
+    cell *c = grid->FirstPt_All();
+    std::vector<pion_flt> buf(3 * par.nvar);
+    pion_flt *p = &buf[0], *ui = &buf[par.nvar], *uf = &buf[2 * par.nvar];
+    double tt = 0.;
+    int err = 0;
+    do {
+      if (c->isdomain) {
+        err += MP->TimeUpdateMP(c->P, p, delt, par.gamma, 0, &tt);
+        solver->PtoU(c->P, ui, par.gamma);
+        solver->PtoU(p, uf, par.gamma);
+        for (int v = 0; v < par.nvar; v++) c->dU[v] += uf[v] - ui[v];
+      }
+    } while ((c = grid->NextPt_All(c)) != 0);
+    return err;
+  }
+  // calc_timestep::get_mp_timescales_no_radiation (sim_control/calc_timestep.cpp:405-507), limits 1-3
+  // (all of them ask mp_only_cooling for the cooling time only, :445-455)
+  double get_mp_timescales_no_radiation()
+  {
+    double tempdt = 0.0, dt = 1.0e99;
+    class cell *c = grid->FirstPt();
+    do {
+      if (!(c->isbd || !c->isleaf)) {
+        tempdt = MP->timescales(c->Ph, par.gamma, true, false, false);
+        dt = min(dt, tempdt);
+      }
+    } while ((c = grid->NextPt(c)) != 0);
+    return dt;
+  }
+  // first_order_update / second_order_update (:151-250); the microphysics dU only with the real MP object
   void stage(double dt, int space_ooa, int is_full)
   {
     solver->Setdt(dt);
     par.dt = dt;
+    if (real_mp && par.EP.cooling) calc_noRT_microphysics_dU(dt);
     solver->preprocess_data(space_ooa, par, grid);
     set_dynamics_dU(dt, space_ooa);
     solver->PostProcess_dU(dt, space_ooa, par, grid);
@@ -762,7 +808,7 @@ int ref_calc_dt(void *h, double *t_dyn, double *t_mp)
 {
   RefSim *s = (RefSim *)h;
   *t_dyn = s->calc_dynamics_dt();
-  *t_mp = 1.0e99;
+  *t_mp = (s->real_mp && s->par.EP.MP_timestep_limit >= 1 && s->par.EP.MP_timestep_limit <= 3) ? s->get_mp_timescales_no_radiation() : 1.0e99;
   return 0;
 }
 int ref_set_glm_speeds(void *h, double dt, double dx, double cr)

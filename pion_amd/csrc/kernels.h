@@ -122,6 +122,7 @@ struct CoolTestArgs {
   int launch_flux_test(const FluxTestArgs &a, hipStream_t s);      \
   int launch_cool_update(const CoolTestArgs &a, hipStream_t s);    \
   int launch_cool_edot(const CoolTestArgs &a, hipStream_t s);      \
+  int launch_cool_timescale(const CoolTestArgs &a, hipStream_t s); \
   const char *stage_kernel_name(int eq, int ntr, int solver);      \
   }
 

@@ -1134,6 +1134,19 @@ __global__ void k_cool_edot(const CoolTestArgs a)
   if (i >= a.n) return;
   a.edot[i] = Cooling::edot(a.cool, a.rho[i], a.T[i]);
 }
+// mp_only_cooling::timescales (cooling time only) of n independent cells: edot[i] = t_cool
+__global__ void k_cool_timescale(const CoolTestArgs a)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const double *p = a.Pin + (long)i * a.nvar;
+  a.edot[i] = Cooling::timescale(a.cool, p[0], p[1], a.gamma);
+}
+int launch_cool_timescale(const CoolTestArgs &a, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_cool_timescale, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
 int launch_cool_update(const CoolTestArgs &a, hipStream_t s)
 {
   hipLaunchKernelGGL(k_cool_update, dim3((a.n + 255) / 256), dim3(256), 0, s, a);

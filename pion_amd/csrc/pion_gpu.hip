@@ -1422,9 +1422,18 @@ static int cool_go(Handle *h, int n, double dt, const double *Pin, double *Pout,
     HCHECK(h, hipMemcpy(d0, Pin, nb, hipMemcpyHostToDevice));
     a.Pin = d0;
     a.Pout = d1;
-    rc = h->cfg.strict_fp ? fp_strict::launch_cool_update(a, h->stream) : fp_fast::launch_cool_update(a, h->stream);
-    HCHECK(h, hipStreamSynchronize(h->stream));
-    HCHECK(h, hipMemcpy(Pout, d1, nb, hipMemcpyDeviceToHost));
+    if (edot) {  // cooling time of each state (edot = the output array, n doubles)
+      HCHECK(h, hipMalloc(&d2, sizeof(double) * (size_t)n));
+      a.edot = d2;
+      rc = h->cfg.strict_fp ? fp_strict::launch_cool_timescale(a, h->stream) : fp_fast::launch_cool_timescale(a, h->stream);
+      HCHECK(h, hipStreamSynchronize(h->stream));
+      HCHECK(h, hipMemcpy(edot, d2, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    else {
+      rc = h->cfg.strict_fp ? fp_strict::launch_cool_update(a, h->stream) : fp_fast::launch_cool_update(a, h->stream);
+      HCHECK(h, hipStreamSynchronize(h->stream));
+      HCHECK(h, hipMemcpy(Pout, d1, nb, hipMemcpyDeviceToHost));
+    }
   }
   else {
     const size_t nb = sizeof(double) * (size_t)n;
@@ -1450,6 +1459,10 @@ int pion_gpu_cooling_update(void *handle, int n, double dt, const double *P_in, 
 int pion_gpu_cooling_edot(void *handle, int n, const double *rho, const double *T, double *edot)
 {
   return cool_go(use(handle), n, 0.0, nullptr, nullptr, rho, T, edot);
+}
+int pion_gpu_cooling_timescale(void *handle, int n, const double *P_in, double *t_cool)
+{
+  return cool_go(use(handle), n, 0.0, P_in, nullptr, nullptr, nullptr, t_cool);
 }
 
 int pion_gpu_enable_timing(void *handle, int on)

@@ -63,6 +63,7 @@ def load_library():
     lib.pion_gpu_interface_flux.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]
     lib.pion_gpu_cooling_update.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp, _dp]
     lib.pion_gpu_cooling_edot.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+    lib.pion_gpu_cooling_timescale.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     lib.pion_gpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.pion_gpu_get_timing.argtypes = [C.c_void_p, _dp, C.c_int]
     _lib = lib
@@ -77,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "pion_gpu_set_cooling_tables", "pion_gpu_update_bcs", "pion_gpu_calc_dt",
     "pion_gpu_set_glm_speeds", "pion_gpu_stage", "pion_gpu_advance_time", "pion_gpu_halo_count",
     "pion_gpu_pack_halo", "pion_gpu_unpack_halo", "pion_gpu_interface_flux",
-    "pion_gpu_cooling_update", "pion_gpu_cooling_edot", "pion_gpu_enable_timing",
+    "pion_gpu_cooling_update", "pion_gpu_cooling_edot", "pion_gpu_cooling_timescale", "pion_gpu_enable_timing",
     "pion_gpu_calc_dt_device", "pion_gpu_read_dt", "pion_gpu_get_stream", "pion_gpu_dt_request", "pion_gpu_dt_wait",
     "pion_gpu_halo_spans", "pion_gpu_halo_begin", "pion_gpu_halo_end",
     "pion_gpu_get_timing", "pion_gpu_stage_part", "pion_gpu_set_comm_stream", "pion_gpu_set_jet",
@@ -238,6 +239,12 @@ class GpuSim:
         T = np.ascontiguousarray(T, dtype=np.float64)
         out = np.zeros_like(rho)
         self._chk(self.lib.pion_gpu_cooling_edot(self.h, rho.size, _p(rho), _p(T), _p(out)), "cooling_edot")
+        return out
+
+    def cooling_timescale(self, Pin):
+        Pin = np.ascontiguousarray(Pin, dtype=np.float64)
+        out = np.zeros(Pin.shape[0])
+        self._chk(self.lib.pion_gpu_cooling_timescale(self.h, Pin.shape[0], _p(Pin), _p(out)), "cooling_timescale")
         return out
 
     def enable_timing(self, on=True):

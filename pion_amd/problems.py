@@ -393,3 +393,27 @@ def random_states(rng, n, eqntype, ntracer=0, kind="mixed"):
         R[6 * k:7 * k, abi.VX] = L[6 * k:7 * k, abi.VX] + 6.0   # strong rarefaction
         R[7 * k:8 * k, abi.VX] = L[7 * k:8 * k, abi.VX] - 6.0   # strong compression
     return L, R
+
+
+def cooling_blast3d(n, strict_fp=0, solver=abi.FLUX_FVS):
+    """Wind3D's equations, solver, microphysics and units (test_problems/Wind3D/params_Wind3D_n0128_l2.txt:
+    Euler + 1 tracer, FVS, FKJ98 eta 0.15, cooling 8 with the cooling-time step limit, T in [5e3, 1e8],
+    reflecting / one-way-outflow) WITHOUT the stellar-wind source: a hot dense bubble (2e6 K, 20x the ambient
+    density, tracer 1) at the origin of the photoionised ambient medium, so that both the radiative losses of
+    the bubble and the heating/cooling balance of the ambient gas act from the first step.  This is the
+    cooling configuration the reference objects can run end to end (the wind source needs GSL there)."""
+    L = 3.160064e18
+    bcs = ["reflecting", "one-way-outflow"] * 3
+    cfg = abi.make_config(3, [n, n, n], abi.EQEUL, solver, ntracer=1, artvisc=abi.AV_FKJ98_1D, etav=0.15,
+                          gamma=1.6666666666666667, cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(L, L, L), bcs=bcs,
+                          refvec=[1.0e-24, 1.0e-13, 1.0e6, 1.0e6, 1.0e6, 1.0], min_temp=5.0e3, max_temp=1.0e8,
+                          cooling=abi.COOL_WSS09_CIE_LINE_HEAT_COOL, mp_timestep_limit=1, strict_fp=strict_fp)
+    P = alloc(cfg)
+    X, Y, Z = mesh(cfg)
+    r2 = X * X + Y * Y + Z * Z
+    inside = r2 < (0.3 * L) ** 2
+    mu_over_kb = 0.609 * 1.672621898e-24 / 1.38064852e-16
+    P[abi.RO] = np.where(inside, 20.0, 1.0) * 2.124229813e-24
+    P[abi.PG] = P[abi.RO] * np.where(inside, 2.0e6, 7.5e3) / mu_over_kb
+    P[5] = np.where(inside, 1.0, 0.0)
+    return cfg, P

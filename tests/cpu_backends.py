@@ -32,6 +32,87 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+_curves_installed = False
+
+
+def install_ref_rate_curves():
+    """Hands the three spline-backed rate curves (WSS09 metals-only CIE cooling, Hummer94 case-B
+    recombination rate and total H+ cooling) to the test doubles of oracle/ref_cooling.cpp.  The curves
+    are the PRODUCT's (pion_amd/host/cooling_tables.cpp); their values are what stays parity-unpinned.
+    From here on a "ref" handle with cfg.cooling != 0 holds the reference's own mp_only_cooling."""
+    global _curves_installed
+    if _curves_installed:
+        return
+    from pion_amd import cooling
+    host = cooling._load()
+    ref = C.CDLL(REF_SO)
+    ptr = [C.cast(getattr(host, f), C.c_void_p) for f in
+           ("pion_host_cooling_rate_wss09", "pion_host_hii_rrr", "pion_host_hii_total_cooling")]
+    ref.ref_cooling_set_rate_curves.restype = None
+    ref.ref_cooling_set_rate_curves(*ptr)
+    _curves_installed = True
+
+
+class RefCooling:
+    """The reference's mp_only_cooling object alone (oracle/ref_cooling.cpp), EP.cooling = 8."""
+
+    def __init__(self, min_temp, max_temp, gamma, nvar=5, ntracer=0):
+        install_ref_rate_curves()
+        self.lib = C.CDLL(REF_SO)
+        self.h = C.c_void_p()
+        self.nvar = nvar
+        rc = self.lib.ref_cooling_create(C.c_double(min_temp), C.c_double(max_temp), C.c_double(gamma),
+                                         C.c_int(nvar), C.c_int(ntracer), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("ref_cooling_create %d" % rc)
+
+    def close(self):
+        if self.h:
+            self.lib.ref_cooling_destroy.restype = None
+            self.lib.ref_cooling_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def tables(self, nT=200):
+        T, tabs, sl = np.zeros(nT), np.zeros((5, nT)), np.zeros((5, nT))
+        rc = self.lib.ref_cooling_tables(self.h, C.c_int(nT), _p(T), _p(tabs), _p(sl))
+        if rc != 0:
+            raise RuntimeError("the reference's table has %d points" % rc)
+        return T, tabs, sl
+
+    def limits(self):
+        out = np.zeros(3)
+        self.lib.ref_cooling_limits.restype = None
+        self.lib.ref_cooling_limits(self.h, _p(out))
+        return out
+
+    def edot(self, rho, T):
+        rho = np.ascontiguousarray(rho, dtype=np.float64)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        out = np.zeros_like(rho)
+        self.lib.ref_cooling_edot(self.h, C.c_int(rho.size), _p(rho), _p(T), _p(out))
+        return out
+
+    def update(self, Pin, dt):
+        Pin = np.ascontiguousarray(Pin, dtype=np.float64)
+        out, Tf = np.zeros_like(Pin), np.zeros(Pin.shape[0])
+        rc = self.lib.ref_cooling_update(self.h, C.c_int(Pin.shape[0]), C.c_double(dt), _p(Pin), _p(out), _p(Tf))
+        if rc != 0:
+            raise RuntimeError("TimeUpdateMP returned %d" % rc)
+        return out, Tf
+
+    def timescale(self, Pin):
+        Pin = np.ascontiguousarray(Pin, dtype=np.float64)
+        out = np.zeros(Pin.shape[0])
+        self.lib.ref_cooling_timescale(self.h, C.c_int(Pin.shape[0]), _p(Pin), _p(out))
+        return out
+
+
 class CpuSim:
     """One handle of the oracle ("orc") or of the reference harness ("ref")."""
 

@@ -147,8 +147,76 @@ def main_c():
     print("endstate.npz", os.path.getsize(os.path.join(HERE, "endstate.npz")) // 1024, "KiB")
 
 
+def main_d():
+    """cooling_kat.npz, steps_c.npz, endstate_c.npz: the REFERENCE's own mp_only_cooling (compiled from
+    microphysics/mp_only_cooling.cpp; oracle/ref_cooling.cpp) -- its look-up tables, Edot, TimeUpdateMP and
+    timescales on seeded inputs, and whole steps / a 60-step run of the cooling configuration with it as the
+    global MP object.  The three spline-backed rate curves are supplied by this script from the product's table
+    builder (their values are the part that stays parity-unpinned).  `make_golden.py d`."""
+    from cpu_backends import RefCooling, install_ref_rate_curves
+    from pion_amd import cooling
+    rng = np.random.default_rng(20240613)
+    out = {}
+    for k, (tmin, tmax) in enumerate(gc.COOL_RANGES):
+        cfg = gc.cool_cfg(k)
+        with RefCooling(tmin, tmax, gc.COOL_GAMMA, gc.COOL_NVAR, 1) as r, CpuSim(cfg, "orc") as o:
+            T, tabs, sl = r.tables()
+            o.set_cooling_tables(T, tabs, sl)
+            key = "r%d_" % k
+            out[key + "T"], out[key + "tabs"], out[key + "slopes"], out[key + "limits"] = T, tabs, sl, r.limits()
+            rho, Te = gc.cool_edot_inputs(rng, tmin, tmax, T)
+            out[key + "edot_rho"], out[key + "edot_T"], out[key + "edot"] = rho, Te, r.edot(rho, Te)
+            P, _ = gc.cool_states(rng, tmin, tmax)
+            out[key + "P"] = P
+            out[key + "tcool"] = r.timescale(P)
+            for j, dt in enumerate(gc.COOL_DTS):
+                # the reference exits the process when its integrator gives up: keep the states the oracle
+                # (screened one by one) integrates, and let the reference run exactly those
+                ok = np.zeros(P.shape[0], dtype=bool)
+                for i in range(P.shape[0]):
+                    try:
+                        o.cooling_update(P[i:i + 1], dt)
+                        ok[i] = True
+                    except RuntimeError:
+                        pass
+                Pout, Tf = r.update(P[ok], dt)
+                out[key + "upd%d_ok" % j], out[key + "upd%d_P" % j], out[key + "upd%d_Tf" % j] = ok, Pout, Tf
+                print("range %d dt %.0e: %d of %d states integrated" % (k, dt, ok.sum(), ok.size))
+    np.savez_compressed(os.path.join(HERE, "cooling_kat.npz"), **out)
+    # whole steps and a long run with the reference's mp_only_cooling as MP
+    install_ref_rate_curves()
+    out = {}
+    for name in gc.STEP_CASES_C:
+        cfg, P = gc.step_case_c(name)
+        with CpuSim(cfg, "ref") as r:
+            sc = driver.SimControl(r, cfg)
+            sc.init(P)
+            dts = []
+            for _ in range(gc.NSTEPS):
+                dts.append(sc.calculate_timestep())
+                sc.advance_time()
+            out[name + "_dt"] = np.array(dts)
+            out[name + "_P"] = r.download(0)
+    np.savez_compressed(os.path.join(HERE, "steps_c.npz"), **out)
+    out = {}
+    for name in gc.END_CASES_C:
+        cfg, P, tf, nmax = gc.end_case_c(name)
+        with CpuSim(cfg, "ref") as r:
+            n, t, dts = gc.end_run(r, cfg, P, tf, nmax)
+            A = r.download(0)
+        tot, _ = gc.conserved_totals(cfg, A)
+        out[name + "_n"], out[name + "_t"], out[name + "_dt"] = np.array(n), np.array(t), dts
+        out[name + "_P"], out[name + "_tot"] = A, tot
+        print("%-22s %4d steps to t = %.6g" % (name, n, t))
+    np.savez_compressed(os.path.join(HERE, "endstate_c.npz"), **out)
+    for f in ("cooling_kat.npz", "steps_c.npz", "endstate_c.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "b":
+    if len(sys.argv) > 1 and sys.argv[1] == "d":
+        main_d()
+    elif len(sys.argv) > 1 and sys.argv[1] == "b":
         main_b()
     elif len(sys.argv) > 1 and sys.argv[1] == "c":
         main_c()
@@ -156,3 +224,4 @@ if __name__ == "__main__":
         main()
         main_b()
         main_c()
+        main_d()

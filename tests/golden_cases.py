@@ -303,3 +303,64 @@ def ode_inputs(rng, n=300):
     tcool = E0 / ode_cie(T0)
     dts = tcool * 10.0 ** rng.uniform(-4, 0.7, n)
     return np.ascontiguousarray(E0), np.ascontiguousarray(dts)
+
+
+# ---- cooling known-answer vectors against the REFERENCE's mp_only_cooling (cooling_kat.npz) -------------
+# (min_temp, max_temp) of EP: Wind3D's range; a range whose limits mp_only_cooling.cpp:140-146 overrides
+# (MinT_allowed 1e-2 -> 1, MaxT_allowed 5e10 -> 1e8, while the table still spans [1e-2, 5e10]); a cold range
+COOL_RANGES = [(5.0e3, 1.0e8), (1.0e-2, 5.0e10), (1.0e1, 1.0e7)]
+COOL_GAMMA = 5.0 / 3.0
+COOL_NVAR = 6   # Euler + 1 tracer, as Wind3D
+
+
+def cool_cfg(rng_idx, strict_fp=1):
+    tmin, tmax = COOL_RANGES[rng_idx]
+    return abi.make_config(3, [4, 4, 4], abi.EQEUL, abi.FLUX_FVS, ntracer=1, xmax=(1, 1, 1), gamma=COOL_GAMMA,
+                           cooling=abi.COOL_WSS09_CIE_LINE_HEAT_COOL, min_temp=tmin, max_temp=tmax,
+                           mp_timestep_limit=1, strict_fp=strict_fp)
+
+
+def cool_edot_inputs(rng, tmin, tmax, Tgrid, n=1000):
+    """(rho, T) pairs: log-uniform, half a decade beyond either end of the table, plus exact table nodes
+    and their neighbours in floating point (the bisection's `<` at a node)"""
+    rho = 10.0 ** rng.uniform(-26, -19, n)
+    T = 10.0 ** rng.uniform(np.log10(tmin) - 0.5, np.log10(tmax) + 0.5, n)
+    k = rng.integers(0, Tgrid.size, 60)
+    T[:60] = Tgrid[k]
+    T[60:80] = np.nextafter(Tgrid[k[:20]], 0.0)
+    T[80:100] = np.nextafter(Tgrid[k[20:40]], np.inf)
+    return rho, T
+
+
+def cool_states(rng, tmin, tmax, n=500):
+    """primitive states (Euler + tracer) at temperatures from a decade below MinTemperature to half a decade above
+    MaxTemperature"""
+    P = np.zeros((n, COOL_NVAR))
+    P[:, abi.RO] = 10.0 ** rng.uniform(-25, -20, n)
+    T = 10.0 ** rng.uniform(np.log10(max(tmin, 1.0)) - 1.0, np.log10(min(tmax, 1.0e8)) + 0.5, n)
+    P[:, abi.PG] = P[:, abi.RO] * T / ODE_MU_TOT_OVER_KB
+    P[:, abi.VX:abi.VZ + 1] = rng.normal(0, 1.0e6, (n, 3))
+    P[:, 5] = rng.uniform(0, 1, n)
+    return P, T
+
+
+COOL_DTS = [1.0e3, 1.0e9, 3.0e10, 1.0e12]   # seconds: Euler shortcut ... many cooling times
+
+
+STEP_CASES_C = ["cool_fvs_3d", "cool_roe_3d"]        # steps_c.npz: whole steps with the reference's mp_only_cooling
+END_CASES_C = ["cool3d_n20"]                         # endstate_c.npz
+
+
+def step_case_c(name, strict_fp=1):
+    if name == "cool_fvs_3d":
+        return problems.cooling_blast3d(12, strict_fp=strict_fp)
+    if name == "cool_roe_3d":
+        return problems.cooling_blast3d(10, strict_fp=strict_fp, solver=abi.FLUX_RSroe)
+    raise KeyError(name)
+
+
+def end_case_c(name, strict_fp=1):
+    if name == "cool3d_n20":
+        cfg, P = problems.cooling_blast3d(20, strict_fp=strict_fp)
+        return cfg, P, 1.0e30, 60
+    raise KeyError(name)
