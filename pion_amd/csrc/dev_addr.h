@@ -54,4 +54,34 @@ PDEV unsigned pin_v(unsigned x)
   asm volatile("" : "+v"(x));
   return x;
 }
+// Neighbour-lane exchange by DPP wave shifts (gfx9: v_mov_b32_dpp ... wave_shl:1 / wave_shr:1, two per double):
+// lane i receives lane i+1's (lane_next) or lane i-1's (lane_prev) value.  Same data movement as
+// __shfl_down(x, 1, 64) / __shfl_up(x, 1, 64), which the compiler turns into ds_bpermute_b32 (an LDS-pipeline
+// round trip each, behind an s_waitcnt lgkmcnt) -- here it is a 32-bit VALU move with no wait.  The lane at the
+// end of the wavefront keeps its own value (bound_ctrl off), as __shfl_* does.
+#ifndef PION_DPP_SHIFT
+#define PION_DPP_SHIFT 1
+#endif
+PDEV double lane_next(const double x)
+{
+#if PION_DPP_SHIFT
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#else
+  return __shfl_down(x, 1, 64);
+#endif
+}
+PDEV double lane_prev(const double x)
+{
+#if PION_DPP_SHIFT
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#else
+  return __shfl_up(x, 1, 64);
+#endif
+}
 #endif

@@ -920,7 +920,7 @@ __global__ __launch_bounds__(256) void k_prepass_hlld_march(const PrepassArgs a)
     double pn3[3], pp3[3];
     // x neighbours from the neighbouring lanes (a cell on an x face of the array takes itself; the halo lanes'
     // own results are not written)
-    const double pl_ = __shfl_up(p0, 1, 64), pr_ = __shfl_down(p0, 1, 64);
+    const double pl_ = lane_prev(p0), pr_ = lane_next(p0);
     pn3[0] = xl ? pl_ : p0;
     pp3[0] = xh ? pr_ : p0;
     pn3[1] = ldu(Pk, qym);

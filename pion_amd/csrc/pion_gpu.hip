@@ -665,6 +665,7 @@ int pion_gpu_upload(void *handle, const double *P_soa)
   HCHECK(h, hipStreamSynchronize(h->stream));
   h->ph_valid = false;
   h->dt_cached = false;
+  h->dt_requested = false;   // a read-back requested for the previous state is void
   return 0;
 }
 
@@ -694,6 +695,7 @@ int pion_gpu_bind_device_state(void *handle, void *dP, void *dPh)
   h->dPh = (double *)dPh;
   h->ph_valid = false;
   h->dt_cached = false;
+  h->dt_requested = false;
   return 0;
 }
 void *pion_gpu_device_ptr(void *handle, int which)
@@ -727,6 +729,7 @@ int pion_gpu_synchronize(void *handle)
 int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double *states)
 {
   Handle *h = use(handle);
+  h->dt_cached = false;   // the ISBD flags decide which cells enter the time-step reduction
   hipFree(h->dwind_idx);
   hipFree(h->dwind_state);
   h->dwind_idx = nullptr;
@@ -750,6 +753,7 @@ int pion_gpu_set_wind_cells(void *handle, long n, const long *idx, const double 
 int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
 {
   Handle *h = use(handle);
+  h->dt_cached = false;   // (cell flags change)
   const pion_gpu_config &cfg = h->cfg;
   const GridDesc &g = h->g;
   const bool cart3d = (cfg.ndim == 3 && cfg.coord_sys == 1 && cfg.eqntype == PION_EQEUL);
@@ -807,6 +811,7 @@ int pion_gpu_set_jet(void *handle, int jetradius, const double *jetstate)
 int pion_gpu_set_cooling_tables(void *handle, int nT, const double *T, const double *tabs, const double *slopes)
 {
   Handle *h = use(handle);
+  h->dt_cached = false;   // t_mp depends on the tables
   if (nT < 2 || nT > PION_COOL_NT_MAX) {
     // (k_cooling_dE keeps the tables in LDS: 11 x PION_COOL_NT_MAX doubles; mp_only_cooling builds 200 points)
     h->err = "cooling tables: 2 <= nT <= 256 required";

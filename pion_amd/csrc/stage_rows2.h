@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             for (int v = 0; v < NV; v++) {
               eL[v] = q0[v] + sx[v] * 0.5;
               const double em = q0[v] - sx[v] * 0.5;
-              eR[v] = __shfl_down(em, 1, 64);
+              eR[v] = lane_next(em);
             }
             if constexpr (MHD) {
               bnm = qm[qBN];
@@ -291,15 +291,15 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
 #pragma unroll
             for (int v = 0; v < NV; v++) {
               eL[v] = q0[v];
-              eR[v] = __shfl_down(q0[v], 1, 64);
+              eR[v] = lane_next(q0[v]);
             }
             if constexpr (MHD) {
               // first order: the x neighbours are only needed for B_n and psi, and those are the
               // neighbouring lanes' own cell values (the end lanes are halo lanes, their result is unused)
-              bnm = __shfl_up(q0[qBN], 1, 64);
+              bnm = lane_prev(q0[qBN]);
               bnp = eR[qBN];
               if constexpr (EQ == EQGLM) {
-                sim = __shfl_up(q0[qSI], 1, 64);
+                sim = lane_prev(q0[qSI]);
                 sip = eR[qSI];
               }
             }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
         if (t == 0) {
           double Fm[NV];
 #pragma unroll
-          for (int v = 0; v < NV; v++) Fm[v] = __shfl_up(f[v], 1, 64);
+          for (int v = 0; v < NV; v++) Fm[v] = lane_prev(f[v]);
           apply_axis<EQ, NV>(dU, q0, bnm, sim, bnp, sip, Fm, f, dt, dx);
         }
         else if (t == 1) {

@@ -15,6 +15,11 @@
 // tools/interpolate.h -> GSL.  In a PION build the class below is a base of, or a member of, a
 // `class sim_control_gpu : public sim_control` whose advance_time / calculate_timestep forward to it.)
 //
+// Boundaries translated: external PERIODIC, OUTFLOW, INFLOW, REFLECTING, FIXED, ONEWAY_OUT, DMACH, AXISYMMETRIC,
+// JETREFLECT; internal DMACH2, JETBC (JP.jetradius / JP.jetstate), STWIND with constant winds (the cells' state at
+// gather time).  Any other boundary type throws -- nothing is dropped silently.  With EP.cooling the look-up
+// tables are built by pion_host_build_cooling_tables (link libpion_host.so) and handed to the device.
+//
 // The state lives on the device between steps; cell::P / Ph are gathered once (gather_and_upload) and
 // scattered back when the host needs them (download_and_scatter: before output, at the end).
 #ifndef PION_GPU_BRIDGE_H
@@ -56,6 +61,7 @@ class pion_gpu_bridge {
   void *h_;
   long ncell_;
   std::vector<double> soa_;
+  std::vector<class cell *> wind_cells_;   // cells of STWIND boundaries; their state is captured at gather time
 };
 
 #endif

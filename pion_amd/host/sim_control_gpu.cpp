@@ -73,6 +73,11 @@ int sim_control_gpu::request_next_dt()
 int sim_control_gpu::Init(const double *P_soa, double simtime)
 {
   T.simtime = simtime;
+  // a second Init on the same object (restart, new problem): the time-step read-back requested at the end of
+  // the last advance_time() belongs to the old state -- discard it here, in the communicator and (upload) in
+  // the library, so that calculate_timestep() reduces the state uploaded now
+  dt_requested_ = false;
+  if (comm_) comm_->reset();
   int err = pion_gpu_upload(h_, P_soa);
   // assign_boundary_data + TimeUpdateInternalBCs/ExternalBCs (sim_init.cpp:246-267)
   err += update_boundaries(cfg.tm_ooa, cfg.tm_ooa, 1);
@@ -173,6 +178,15 @@ int pion_host_sim_init(void *s, const double *P, double simtime, double finishti
   c->T.finishtime = finishtime;
   c->T.first_step_dt_limit = first_dt_limit;
   return c->Init(P, simtime);
+}
+// restart: step counter and the previous step (SimParams::timestep / last_dt, read back from a snapshot header);
+// a fresh problem on a re-used object: (0, 1e100)
+int pion_host_sim_set_time(void *s, int timestep, double last_dt)
+{
+  auto *c = static_cast<pion_host::sim_control_gpu *>(s);
+  c->T.timestep = timestep;
+  c->T.last_dt = last_dt;
+  return 0;
 }
 int pion_host_sim_time_int(void *s, int nsteps, double *simtime, double *last_dt)
 {

@@ -150,6 +150,12 @@ int slab_comm_rccl::allreduce_min(double *t_dyn, double *t_mp)
   return pion_gpu_dt_wait(h_, t_dyn, t_mp);
 }
 
+int slab_comm_rccl::reset()
+{
+  requested_ = false;
+  return finish();
+}
+
 }  // namespace pion_host
 
 // ---- C view (ctypes: tests, bench) ------------------------------------------------------------

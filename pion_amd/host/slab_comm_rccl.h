@@ -48,6 +48,8 @@ class slab_comm_rccl {
   // it (requesting first if nobody has) -- the single host synchronisation of a step
   int request_min();
   int allreduce_min(double *t_dyn, double *t_mp);
+  // new state uploaded (sim_control_gpu::Init): complete an exchange in flight, forget a pending request_min()
+  int reset();
 
   bool has_neighbours() const { return up_ >= 0 || down_ >= 0; }
   const std::string &last_error() const { return err_; }

@@ -38,6 +38,7 @@ def load_host_library():
     h.pion_host_sim_handle.restype = C.c_void_p
     h.pion_host_sim_init.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, C.c_double]
     h.pion_host_sim_time_int.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+    h.pion_host_sim_set_time.argtypes = [C.c_void_p, C.c_int, C.c_double]
     h.pion_host_sim_step.argtypes = [C.c_void_p, _dp]
     h.pion_host_sim_download.argtypes = [C.c_void_p, C.c_int, _dp]
     h.pion_host_sim_set_comm.argtypes = [C.c_void_p, C.c_void_p]
@@ -100,7 +101,9 @@ class HostSim:
     def gpu_handle(self):
         return self.lib.pion_host_sim_handle(self.s)
 
-    def init(self, P, simtime=0.0, finishtime=1e300, first_step_dt_limit=None):
+    def init(self, P, simtime=0.0, finishtime=1e300, first_step_dt_limit=None, timestep=0, last_dt=1e100):
+        """sim_init::Init; on a restart pass the snapshot's simtime / timestep / last_dt"""
+        self.lib.pion_host_sim_set_time(self.s, int(timestep), float(last_dt))
         Pc = np.ascontiguousarray(P, dtype=np.float64).reshape(-1)
         rc = self.lib.pion_host_sim_init(self.s, Pc.ctypes.data_as(_dp), simtime, finishtime,
                                          -1.0 if first_step_dt_limit is None else first_step_dt_limit)

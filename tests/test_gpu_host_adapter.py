@@ -40,3 +40,43 @@ def test_cpp_time_int_equals_python_driver():
             sc.time_int(4)
             assert sc.simtime == t.value and sc.last_dt == ldt.value
             assert np.array_equal(g.download(0).reshape(-1), out)
+
+
+def test_second_init_on_the_same_object_does_not_see_the_old_time_step():
+    """advance_time() ends by requesting the next step's minima; a second Init (new problem, restart) must not
+    consume that request: the first dt after it comes from the state uploaded last."""
+    from pion_amd import host_rccl
+    cfg, P = problems.mhd_blastwave(20, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
+    P2 = P.copy()
+    P2[abi.PG] *= 7.0          # a different problem: shorter time step
+    P2[abi.VX] += 0.3
+    with host_rccl.HostSim(cfg, 0) as fresh:
+        fresh.init(P2)
+        nf, tf, lf = fresh.time_int(3)
+        want = fresh.download(0)
+    with host_rccl.HostSim(cfg, 0) as s:
+        s.init(P)
+        s.time_int(2)
+        s.init(P2)                       # same object, new state, time reset
+        n, t, l = s.time_int(3)
+        got = s.download(0)
+    assert (n, t, l) == (nf, tf, lf)
+    assert np.array_equal(got, want)
+
+
+def test_restart_through_the_host_driver_is_bit_identical():
+    """init, 2 steps, download, Init again from the downloaded state with the time bookkeeping of a snapshot,
+    3 more steps == 5 uninterrupted steps"""
+    from pion_amd import host_rccl
+    cfg, P = problems.hd_blast_octant(20, 3, solver=abi.FLUX_RSroe, strict_fp=1, nzones=3.0)
+    with host_rccl.HostSim(cfg, 0) as a:
+        a.init(P)
+        a.time_int(5)
+        want = a.download(0)
+    with host_rccl.HostSim(cfg, 0) as b:
+        b.init(P)
+        n, t, l = b.time_int(2)
+        mid = b.download(0)
+        b.init(mid, simtime=t, timestep=2, last_dt=l)
+        b.time_int(3)
+        assert np.array_equal(b.download(0), want)
