@@ -65,6 +65,7 @@ struct StageArgs {
   unsigned long long *dtres;  // k_stage_rows2, full step: min t_dyn / t_mp bits of the new state (or null)
   double cfl;
   int dt_mp;          // also reduce the cooling time (EP.MP_timestep_limit)
+  int plain_cells;    // every on-grid cell is an ordinary domain cell (no stellar-wind cells): flags need not be read
   CoolDev cool;
 };
 

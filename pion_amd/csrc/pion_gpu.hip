@@ -79,6 +79,184 @@ __global__ __launch_bounds__(256) void k_bc_periodic_all(double *T, const GridDe
   for (int v = 0; v < nvar; v++) T[v * g.ncell + c] = T[v * g.ncell + sc];
 }
 
+// Every external face of a grid in ONE launch, any mix of boundary types (what k_bc_periodic_all does for the
+// all-periodic case).  The reference updates the faces one after the other in list order XN, XP, YN, YP, ZN, ZP
+// (assign_update_bcs.cpp:185-252); a ghost cell belongs to the list of the HIGHEST axis along which it is a
+// ghost (X lists hold on-grid (y,z) rows, Y lists the full x extent, Z lists the full x-y extent,
+// uniform_grid.cpp:1009-1216), and a corner ghost takes its value from a ghost cell that a lower axis's update has
+// just filled.  That chain of copies always ends on an on-grid cell (or on a constant state), which no boundary
+// update writes: so each thread walks the chain of ITS ghost cell down the axes, reads the terminal cell, and
+// applies the per-face operations (sign flips, one-way clamp, psi rule) on the way back up, lowest axis first --
+// the same values as the six launches, without their ordering.  psi of GLM-MHD follows its own chain: outflow
+// and one-way faces take -psi of the MIRROR cell (outflow_boundaries.cpp:140-152), everything else of the copy
+// source.  Then the internal DMR2 boundary, which the reference applies last (double_Mach_ref_boundaries.cpp:98-147).
+// z faces of kind SLAB (neighbour rank) are left alone.
+struct BCAllArgs {
+  GridDesc g;
+  double *T;
+  int nvar, eqntype, ntracer, ndim;
+  int type[6];
+  double refval[6][PION_MAX_NVAR];
+  double dmr_a0, dmr_t3;
+  int dmr2_cols;              // > 0: internal DMR2 boundary over the first dmr2_cols on-grid columns
+  double dmr2_val[PION_MAX_NVAR];
+};
+
+__global__ __launch_bounds__(256) void k_bc_all(const BCAllArgs a)
+{
+  const GridDesc &g = a.g;
+  const int nd = a.ndim;
+  // ghost cells as three disjoint slabs: A = z ghosts (all x,y), B = y ghosts on on-grid z (all x),
+  // C = x ghosts on on-grid y and z
+  const long nA = (nd == 3) ? (long)2 * g.nbc[2] * g.nga[0] * g.nga[1] : 0;
+  const long nB = (nd >= 2) ? (long)g.ng[2] * 2 * g.nbc[1] * g.nga[0] : 0;
+  const long nC = (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nA + nB + nC) return;
+  int i[3];   // all-cell coordinates (ghosts included)
+  if (t < nA) {
+    i[0] = (int)(t % g.nga[0]);
+    i[1] = (int)((t / g.nga[0]) % g.nga[1]);
+    const int kz = (int)(t / ((long)g.nga[0] * g.nga[1]));
+    i[2] = (kz < g.nbc[2]) ? kz : g.ng[2] + kz;
+  }
+  else if (t < nA + nB) {
+    t -= nA;
+    i[0] = (int)(t % g.nga[0]);
+    const int ky = (int)((t / g.nga[0]) % (2 * g.nbc[1]));
+    i[1] = (ky < g.nbc[1]) ? ky : g.ng[1] + ky;
+    i[2] = (int)(t / ((long)g.nga[0] * 2 * g.nbc[1])) + g.nbc[2];
+  }
+  else {
+    t -= nA + nB;
+    const int kx = (int)(t % (2 * g.nbc[0]));
+    i[0] = (kx < g.nbc[0]) ? kx : g.ng[0] + kx;
+    i[1] = (int)((t / (2 * g.nbc[0])) % g.ng[1]) + g.nbc[1];
+    i[2] = (int)(t / ((long)2 * g.nbc[0] * g.ng[1])) + g.nbc[2];
+  }
+  const long nc = g.ncell;
+  const long c = (long)i[0] + g.sy * i[1] + g.sz * i[2];
+  const bool mhd = (a.eqntype == EQMHD || a.eqntype == EQGLM);
+  const bool glm = (a.eqntype == EQGLM);
+
+  // ---- down the axes: the chain of source cells (s: all variables but psi; p: psi)
+  int s[3] = {i[0], i[1], i[2]}, p[3] = {i[0], i[1], i[2]};
+  int op_type[3] = {0, 0, 0}, op_pos[3] = {0, 0, 0};
+  int const_ax = -1;   // axis whose face gives a constant / analytic state: the chain ends there
+  bool owned = false;
+  for (int ax = nd - 1; ax >= 0; ax--) {
+    const int lo = g.nbc[ax], hi = g.nbc[ax] + g.ng[ax];
+    if (s[ax] >= lo && s[ax] < hi) continue;   // on-grid along this axis
+    const bool pos = (s[ax] >= hi);
+    const int type = a.type[2 * ax + (pos ? 1 : 0)];
+    // the first ghost axis met is the list this cell belongs to: a SLAB (neighbour rank) or unset face there
+    // means the cell is not ours to fill
+    if (!owned && (type == 0 || type == PION_BC_SLAB)) return;
+    owned = true;
+    op_type[ax] = type;
+    op_pos[ax] = pos ? 1 : 0;
+    const int depth = pos ? s[ax] - hi + 1 : lo - s[ax];   // distance from the grid = -isedge
+    if (type == PION_BC_PERIODIC) {
+      s[ax] += pos ? -g.ng[ax] : g.ng[ax];
+      p[ax] = s[ax];
+    }
+    else if (type == PION_BC_INFLOW || type == PION_BC_FIXED || type == PION_BC_DMACH) {
+      const_ax = ax;
+      break;
+    }
+    else if (type == 0 || type == PION_BC_SLAB) {
+      // (an unset face below the owning axis: the source is that ghost cell as it stands)
+      op_type[ax] = 0;
+      break;
+    }
+    else {
+      // outflow, one-way, reflecting, axisymmetric, jet-reflect: every ghost layer copies the FIRST on-grid cell
+      // of the row (outflow_boundaries.cpp:50-59); psi of an outflow / one-way face: the mirror cell
+      s[ax] = pos ? hi - 1 : lo;
+      if (glm && (type == PION_BC_OUTFLOW || type == PION_BC_ONEWAY_OUT)) p[ax] = pos ? hi - depth : lo + depth - 1;
+      else p[ax] = s[ax];
+    }
+  }
+
+  // ---- the terminal state
+  double val[PION_MAX_NVAR];
+  int from = 0;   // first axis whose operation is applied on the way up
+  if (const_ax >= 0) {
+    const int d = 2 * const_ax + op_pos[const_ax];
+    if (op_type[const_ax] == PION_BC_DMACH) {
+      // double_Mach_ref_boundaries.cpp:168-204, position of the ghost cell of the Y list (x may be a ghost)
+      const int ix = s[0] - g.nbc[0], iy = s[1] - g.nbc[1];
+      const double x = g.xmin[0] + (2 * ix + 1) * (0.5 * g.dx);
+      const double y = g.xmin[1] + (2 * iy + 1) * (0.5 * g.dx);
+      const double bpos = a.dmr_a0 + 1.0 / 6.0 + y / a.dmr_t3;
+      if (x <= bpos) {
+        val[0] = 8.0;
+        val[1] = 116.5;
+        val[2] = 7.14470958;
+        val[3] = -4.125;
+        val[4] = 0.0;
+        for (int v = 5; v < a.nvar; v++) val[v] = 0.0;
+        for (int v = a.nvar - a.ntracer; v < a.nvar; v++) val[v] = 1.0;
+      }
+      else {
+        for (int v = 0; v < a.nvar; v++) val[v] = a.refval[d][v];
+      }
+    }
+    else {
+      for (int v = 0; v < a.nvar; v++) val[v] = a.refval[d][v];
+    }
+    from = const_ax + 1;
+  }
+  else {
+    const long sc = (long)s[0] + g.sy * s[1] + g.sz * s[2];
+    for (int v = 0; v < a.nvar; v++) val[v] = a.T[v * nc + sc];
+    if (glm) {
+      const long pc = (long)p[0] + g.sy * p[1] + g.sz * p[2];
+      if (pc != sc) val[8] = a.T[8 * nc + pc];
+    }
+  }
+
+  // ---- back up: the operations of the faces, lowest axis first (the order the reference applies them in)
+  for (int ax = from; ax < nd; ax++) {
+    const int type = op_type[ax];
+    if (type == PION_BC_REFLECTING) {
+      // reflecting_boundaries.cpp:34-73,131-153: normal velocity (and normal B) flip sign
+      val[2 + ax] = val[2 + ax] * -1.0;
+      if (mhd) val[5 + ax] = val[5 + ax] * -1.0;
+    }
+    else if (type == PION_BC_AXISYMMETRIC) {
+      // axisymmetric_boundaries.cpp:34-52,98-137 (R = 0 axis): the radial and the theta components
+      val[3] = val[3] * -1.0;
+      val[4] = val[4] * -1.0;
+      if (mhd) {
+        val[6] = val[6] * -1.0;
+        val[7] = val[7] * -1.0;
+      }
+    }
+    else if (type == PION_BC_JETREFLECT) {
+      // jetreflect_boundaries.cpp:32-62: v_n and the two tangential field components
+      val[2 + ax] = val[2 + ax] * -1.0;
+      if (mhd)
+        for (int v = 5; v <= 7; v++)
+          if (v != 5 + ax) val[v] = val[v] * -1.0;
+    }
+    else if (type == PION_BC_OUTFLOW || type == PION_BC_ONEWAY_OUT) {
+      if (type == PION_BC_ONEWAY_OUT) {
+        // oneway_out_boundaries.cpp:75-138
+        const double sg = op_pos[ax] ? 1.0 : -1.0;
+        const double x = val[2 + ax] * sg;
+        val[2 + ax] = sg * ((0.0 < x) ? x : 0.0);
+      }
+      if (glm) val[8] = -val[8];   // GLM_NEGATIVE_BOUNDARY (boundaries.h:21)
+    }
+  }
+  // internal DMR2 boundary: y < 0 ghost cells above the first on-grid columns (x <= 1/6) hold a fixed state
+  if (a.dmr2_cols > 0 && i[1] < g.nbc[1] && i[0] >= g.nbc[0] && i[0] < g.nbc[0] + a.dmr2_cols) {
+    for (int v = 0; v < a.nvar; v++) val[v] = a.dmr2_val[v];
+  }
+  for (int v = 0; v < a.nvar; v++) a.T[v * nc + c] = val[v];
+}
+
 // One thread per ghost cell of one face.  List membership follows UniformGrid::SetupBCs
 // (grid/uniform_grid.cpp:1009-1216): X faces hold on-grid (y,z) rows only, Y faces the full x
 // extent, Z faces the full x-y extent, which together with the X->Y->Z launch order fills the
@@ -866,8 +1044,37 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
                        zwrap, skipx);
   }
   h->xghost_fresh = nullptr;
+  // any other mix of face types, once the boundaries are assigned: ONE launch for all external faces and the
+  // internal DMR2 boundary (k_bc_all); the assignment itself (inflow / fixed states are captured face by face,
+  // after the lower faces were filled) keeps the per-face sequence below
+  const bool one_launch = (!all_periodic && !assign && h->fuse_bc);
+  if (one_launch) {
+    BCAllArgs a;
+    a.g = g;
+    a.T = T;
+    a.nvar = cfg.nvar;
+    a.eqntype = cfg.eqntype;
+    a.ntracer = cfg.ntracer;
+    a.ndim = cfg.ndim;
+    for (int d = 0; d < 6; d++) {
+      a.type[d] = (d < 2 * cfg.ndim) ? cfg.bc_type[d] : 0;
+      for (int v = 0; v < PION_MAX_NVAR; v++) a.refval[d][v] = h->refval[d][v];
+    }
+    a.dmr_a0 = 10.0 * simtime / sin(M_PI / 3.0);
+    a.dmr_t3 = tan(M_PI / 3.0);
+    a.dmr2_cols = (cfg.bc_dmach2 && h->dmr2_cols > 0) ? h->dmr2_cols : 0;
+    for (int v = 0; v < PION_MAX_NVAR; v++) a.dmr2_val[v] = 0.0;
+    a.dmr2_val[0] = 8.0;
+    a.dmr2_val[1] = 116.5;
+    a.dmr2_val[2] = 7.14470958;
+    a.dmr2_val[3] = -4.125;
+    for (int v = cfg.nvar - cfg.ntracer; v < cfg.nvar; v++) a.dmr2_val[v] = 1.0;
+    const long n = ((cfg.ndim == 3) ? (long)2 * g.nbc[2] * g.nga[0] * g.nga[1] : 0)
+                   + ((cfg.ndim >= 2) ? (long)g.ng[2] * 2 * g.nbc[1] * g.nga[0] : 0) + (long)g.ng[2] * g.ng[1] * 2 * g.nbc[0];
+    hipLaunchKernelGGL(k_bc_all, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, a);
+  }
   // TimeUpdateExternalBCs in list order XN,XP,YN,YP,ZN,ZP then DMR2 (assign_update_bcs.cpp:185-252)
-  for (int d = 0; d < 2 * cfg.ndim && !all_periodic; d++) {
+  for (int d = 0; d < 2 * cfg.ndim && !all_periodic && !one_launch; d++) {
     const int type = cfg.bc_type[d];
     if (type == 0 || type == PION_BC_SLAB) continue;
     if (assign) {
@@ -916,7 +1123,7 @@ int pion_gpu_update_bcs(void *handle, double simtime, int cstep, int maxstep, in
     }
     hipLaunchKernelGGL(k_bc_face, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a);
   }
-  if (cfg.bc_dmach2 && h->dmr2_cols > 0) {
+  if (cfg.bc_dmach2 && h->dmr2_cols > 0 && !one_launch) {
     BCArgs a;
     a.g = g;
     a.T = T;
@@ -1144,6 +1351,7 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   a.kz2 = kz2;
   a.kz3 = (kz3 > kz2) ? kz3 : kz2;
   a.zslope_lds = h->zslope_lds;
+  a.plain_cells = (h->nwind == 0) ? 1 : 0;
   a.dE = nullptr;
   // periodic x: k_stage_rows2 writes the x ghost images of its rows (the boundary launch then skips them)
   a.xwrap = (a.use_march != 0 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC

@@ -93,6 +93,12 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #ifndef PION_ROWS2_YWG
 #define PION_ROWS2_YWG 1
 #endif
+#ifndef PION_ROWS2_UNROLL_T
+#define PION_ROWS2_UNROLL_T 0
+#endif
+#ifndef PION_ROWS2_U0
+#define PION_ROWS2_U0 1
+#endif
 
 // workgroups per CU the register allocation aims at
 #ifndef PION_ROWS2_MINWG
@@ -236,6 +242,25 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       }
 #pragma unroll
       for (int v = 0; v < NV; v++) dU[v] = 0.0;
+#if defined(PION_FAST_MATH) && PION_ROWS2_U0
+      // Fast build, second-order stage of a grid without internal-boundary cells: the start-of-step state is
+      // requested HERE, with the row's own loads, and enters as dU = PtoU(P0) -- the new conserved state is then
+      // ((U0 + dU_x) + dU_y) + dU_z instead of the reference's U0 + ((dU_x + dU_y) + dU_z) (same sum up to
+      // rounding; the strict build keeps the reference's order).  At the end of the row, where the reference form
+      // needs P0, a load would be waited for with nothing to overlap it.
+      const bool u0 = PLAIN && !same_pc && !prime && a.plain_cells;
+      if (u0) {
+        const unsigned o = pin_v(off_r);
+        const unsigned zu0 = opaque_zero();
+        const char *const Pcb0 = reinterpret_cast<const char *>(a.Pc) + zu0;
+        double P0[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) P0[v] = ldu_once(Pcb0 + v * ncb, o);
+        E::PtoU(P0, dU, g);
+      }
+#else
+      const bool u0 = false;
+#endif
       if (!PLAIN && !prime && a.dE) {
         // calc_noRT_microphysics_dU (time_integrator.cpp:438-489): only the energy changes; k_cooling
         // left PtoU(p_new)[ERG] - PtoU(P)[ERG] of every domain cell (0 elsewhere)
@@ -243,9 +268,23 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       }
       double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;
 
+#if PION_ROWS2_UNROLL_T
+      // the four tasks of a row (x face, lower y face of the first row, upper y face, upper z face) as four
+      // straight-line copies of the task body -- the flux body inlined in each -- instead of one body in a
+      // uniform loop: the task number is a compile-time constant of each copy, so the sweep-frame permutation,
+      // the edge-state arrays and what happens to the flux need no selects and no copies at a loop join
+      // (The two y tasks share ONE copy, run as a loop of one or two passes: the lower face of a row group and
+      // the upper face of the group below it are the same interface, solved by two wavefronts -- from one copy of
+      // the code both get the same bits in the fast build too, whose FMA contraction may differ between copies.)
+      auto task = [&](auto tc, const int t_run) __attribute__((always_inline)) {
+        constexpr int TC = decltype(tc)::value;
+        const int t = (TC == 12) ? t_run : TC;
+        if (TC == 12) __builtin_assume(t == 1 || t == 2);
+#else
 #pragma unroll 1
       for (int t = prime ? 3 : 0; t < 4; t++) {
         if (t == 1 && r > 0) continue;  // lower y face: flux carried from the previous row
+#endif
         double eL[NV], eR[NV], f[NV], pstar[NV];
         long cl, st;
         int ax;
@@ -559,7 +598,18 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
 #pragma unroll
           for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = f[v];
         }
+#if PION_ROWS2_UNROLL_T
+      };
+      if (!prime) {
+        task(std::integral_constant<int, 0>{}, 0);
+        // lower y face only for the first row of the group (else: the flux carried from the previous row)
+#pragma unroll 1
+        for (int ty = (r == 0) ? 1 : 2; ty < 3; ty++) task(std::integral_constant<int, 12>{}, ty);
       }
+      task(std::integral_constant<int, 3>{}, 3);
+#else
+      }
+#endif
 
       if (!prime && writer && row_ok) {
         const unsigned off = pin_v(off_r), offb = pin_v(offb_r);
@@ -568,8 +618,15 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
         const unsigned zu = opaque_zero();
         const char *const Pcb = reinterpret_cast<const char *>(a.Pc) + zu;
         char *const Ob = reinterpret_cast<char *>(a.out) + zu;
-        const unsigned fl = ldub(reinterpret_cast<const char *>(a.flags) + zu, offb);
+        // (a grid without internal-boundary cells: every on-grid cell is isgd | isdomain | timestep | isleaf)
+        const unsigned fl = (PLAIN && a.plain_cells) ? 29u : ldub(reinterpret_cast<const char *>(a.flags) + zu, offb);
         double P0[NV], Pf[NV];
+        if (u0) {
+          // dU already holds PtoU(P0) + dU: the tail of cell_update (CellAdvanceTime) from there
+          E::UtoP(dU, Pf, a.fc.min_temp, g, MPd{}, err);
+          if constexpr (EQ == EQGLM) Pf[qSI] *= a.glm_damp;
+        }
+        else {
         if (same_pc) {
 #pragma unroll
           for (int v = 0; v < NV; v++) P0[v] = q0[v];
@@ -583,6 +640,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           for (int v = 0; v < NV; v++) Pf[v] = P0[v];
         }
         else cell_update<EQ, NTR>(a, P0, dU, err, Pf, PLAIN);
+        }
 #pragma unroll
         for (int v = 0; v < NV; v++) stu(Ob + v * ncb, off, Pf[v]);
         if (a.xwrap) {

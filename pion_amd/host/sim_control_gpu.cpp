@@ -1,7 +1,7 @@
 // sim_control_gpu.cpp -- see sim_control_gpu.h
 #include "sim_control_gpu.h"
 
-#include "slab_comm_rccl.h"
+#include "slab_comm.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -10,28 +10,29 @@
 
 namespace pion_host {
 
-sim_control_gpu::sim_control_gpu(const pion_gpu_config &c, int device) : cfg(c), h_(nullptr)
+sim_control_gpu::sim_control_gpu(const pion_gpu_config &c, int device, const pion_backend *backend)
+    : cfg(c), be_(backend ? backend : pion_backend_gpu()), h_(nullptr)
 {
-  const int rc = pion_gpu_create(&cfg, device, &h_);
+  const int rc = be_->create(&cfg, device, &h_);
   if (rc != 0) {
     std::string m = h_ ? last_error() : std::string("invalid configuration");
-    if (h_) pion_gpu_destroy(h_);
+    if (h_) be_->destroy(h_);
     h_ = nullptr;
-    throw std::runtime_error("pion_gpu_create failed (" + std::to_string(rc) + "): " + m);
+    throw std::runtime_error(std::string(be_->name) + ": create failed (" + std::to_string(rc) + "): " + m);
   }
 }
 sim_control_gpu::~sim_control_gpu()
 {
-  if (h_) pion_gpu_destroy(h_);
+  if (h_) be_->destroy(h_);
 }
 std::string sim_control_gpu::last_error() const
 {
   char buf[512] = {0};
-  pion_gpu_last_error(h_, buf, sizeof buf);
+  be_->last_error(h_, buf, sizeof buf);
   return buf;
 }
 
-int sim_control_gpu::set_comm(slab_comm_rccl *c)
+int sim_control_gpu::set_comm(slab_comm *c)
 {
   comm_ = c;
   return c ? c->attach(h_) : 0;
@@ -41,17 +42,17 @@ int sim_control_gpu::set_comm(slab_comm_rccl *c)
 // array that was just written; stage() completes it between its two parts
 int sim_control_gpu::update_boundaries(int cstep, int maxstep, int assign)
 {
-  int err = pion_gpu_update_bcs(h_, T.simtime, cstep, maxstep, assign);
+  int err = be_->update_bcs(h_, T.simtime, cstep, maxstep, assign);
   if (comm_ && !err) err += comm_->start(cstep == maxstep ? 0 : 1);
   return err;
 }
 
 int sim_control_gpu::stage(double dt, int space_ooa, int is_full)
 {
-  if (!comm_) return pion_gpu_stage(h_, dt, space_ooa, is_full);
-  int err = pion_gpu_stage_part(h_, dt, space_ooa, is_full, PION_STAGE_INTERIOR);
+  if (!comm_) return be_->stage(h_, dt, space_ooa, is_full);
+  int err = be_->stage_part(h_, dt, space_ooa, is_full, PION_STAGE_INTERIOR);
   err += comm_->finish();
-  err += pion_gpu_stage_part(h_, dt, space_ooa, is_full, PION_STAGE_ZBOUNDARY);
+  err += be_->stage_part(h_, dt, space_ooa, is_full, PION_STAGE_ZBOUNDARY);
   return err;
 }
 
@@ -63,9 +64,7 @@ int sim_control_gpu::finish_halo() { return comm_ ? comm_->finish() : 0; }
 int sim_control_gpu::request_next_dt()
 {
   if (comm_) return comm_->request_min();
-  void *d = nullptr;
-  int err = pion_gpu_calc_dt_device(h_, &d);
-  if (!err) err = pion_gpu_dt_request(h_);
+  const int err = be_->dt_begin(h_);
   dt_requested_ = (err == 0);
   return err;
 }
@@ -78,7 +77,7 @@ int sim_control_gpu::Init(const double *P_soa, double simtime)
   // the library, so that calculate_timestep() reduces the state uploaded now
   dt_requested_ = false;
   if (comm_) comm_->reset();
-  int err = pion_gpu_upload(h_, P_soa);
+  int err = be_->upload(h_, P_soa);
   // assign_boundary_data + TimeUpdateInternalBCs/ExternalBCs (sim_init.cpp:246-267)
   err += update_boundaries(cfg.tm_ooa, cfg.tm_ooa, 1);
   return err;
@@ -91,14 +90,14 @@ int sim_control_gpu::calculate_timestep()
   // (COMM->global_operation_double("MIN", .), sim_control_MPI.cpp:503-504)
   int err;
   if (comm_) err = comm_->allreduce_min(&t_dyn, &t_mp);
-  else if (dt_requested_) err = pion_gpu_dt_wait(h_, &t_dyn, &t_mp);
-  else err = pion_gpu_calc_dt(h_, &t_dyn, &t_mp);
+  else if (dt_requested_) err = be_->dt_wait(h_, &t_dyn, &t_mp);
+  else err = be_->calc_dt(h_, &t_dyn, &t_mp);
   dt_requested_ = false;
   if (err) return err;
   if (T.timestep == 0 && T.first_step_dt_limit > 0.0) t_dyn = std::min(t_dyn, T.first_step_dt_limit);
   T.dt = std::min(t_dyn, t_mp);
   // Set_GLM_Speeds(td, dx, 0.25/dx) with the *dynamical* step (calc_timestep.cpp:119-131)
-  if (cfg.eqntype == PION_EQGLM) err += pion_gpu_set_glm_speeds(h_, t_dyn, cfg.dx, 0.25 / cfg.dx);
+  if (cfg.eqntype == PION_EQGLM) err += be_->set_glm_speeds(h_, t_dyn, cfg.dx, 0.25 / cfg.dx);
   // timestep_checking_and_limiting (calc_timestep.cpp:219-262)
   if (T.dt < T.min_timestep) throw std::runtime_error("Timestep too short!");
   T.dt = std::min(T.dt, 1.3 * T.last_dt);  // TIMESTEP_LIMITING
@@ -158,6 +157,19 @@ int sim_control_gpu::Time_Int(int nsteps)
 // ---- C view of the adapter (used by tests/bench through ctypes) -------------------------------
 static thread_local std::string g_last_exception;
 extern "C" {
+// backend: null = libpion_gpu.so (the product); tests hand in another table (pion_backend.h)
+int pion_host_sim_create_backend(const pion_gpu_config *cfg, int device, const pion_backend *backend, void **sim)
+{
+  try {
+    *sim = new pion_host::sim_control_gpu(*cfg, device, backend);
+    return 0;
+  }
+  catch (const std::exception &e) {
+    *sim = nullptr;
+    g_last_exception = e.what();
+    return PION_GPU_EDEVICE;
+  }
+}
 int pion_host_sim_create(const pion_gpu_config *cfg, int device, void **sim)
 {
   try {
@@ -224,7 +236,7 @@ int pion_host_sim_finish_halo(void *s) { return static_cast<pion_host::sim_contr
 // hand the sim a slab communicator (pion_host_comm_create); call before pion_host_sim_init
 int pion_host_sim_set_comm(void *s, void *comm)
 {
-  return static_cast<pion_host::sim_control_gpu *>(s)->set_comm(static_cast<pion_host::slab_comm_rccl *>(comm));
+  return static_cast<pion_host::sim_control_gpu *>(s)->set_comm(static_cast<pion_host::slab_comm *>(comm));
 }
 // one step at a time (bench.py times K of them between barriers)
 int pion_host_sim_step(void *s, double *dt)

@@ -16,10 +16,11 @@
 #include <string>
 
 #include "../../include/pion_gpu.h"
+#include "pion_backend.h"
 
 namespace pion_host {
 
-class slab_comm_rccl;   // slab_comm_rccl.h
+class slab_comm;   // slab_comm.h: slab_comm_rccl (RCCL over xGMI) or slab_comm_shm (host-staged)
 
 // the slice of SimParams (sim_params.h:200-285) the time loop itself reads/writes
 struct SimTime {
@@ -30,7 +31,8 @@ struct SimTime {
 
 class sim_control_gpu {
  public:
-  sim_control_gpu(const pion_gpu_config &cfg, int device);
+  // backend: what runs below the time loop; null = the product's only one, libpion_gpu.so (pion_backend_gpu())
+  sim_control_gpu(const pion_gpu_config &cfg, int device, const pion_backend *backend = nullptr);
   ~sim_control_gpu();
   sim_control_gpu(const sim_control_gpu &) = delete;
 
@@ -48,13 +50,14 @@ class sim_control_gpu {
   // z-slab of a larger domain: exchange the z ghost planes after every boundary update (under the
   // interior part of the next stage) and min-reduce the time step over the ranks
   // (sim_control_pllel, sim_control_MPI.cpp:482-583; MCMD_boundaries.cpp:122-237)
-  int set_comm(slab_comm_rccl *c);
+  int set_comm(slab_comm *c);
   int update_boundaries(int cstep, int maxstep, int assign);
   int stage(double dt, int space_ooa, int is_full);
   int finish_halo();
   int request_next_dt();
 
-  int download(int which, double *P_soa) { return pion_gpu_download(h_, which, P_soa); }
+  int download(int which, double *P_soa) { return be_->download(h_, which, P_soa); }
+  const pion_backend *backend() const { return be_; }
   void *handle() { return h_; }
   std::string last_error() const;
 
@@ -62,8 +65,9 @@ class sim_control_gpu {
   pion_gpu_config cfg;
 
  private:
+  const pion_backend *be_;
   void *h_;
-  slab_comm_rccl *comm_ = nullptr;
+  slab_comm *comm_ = nullptr;
   bool dt_requested_ = false;
 };
 

@@ -164,7 +164,7 @@ int pion_host_comm_unique_id(void *out128) { return pion_host::slab_comm_rccl::g
 int pion_host_comm_create(int rank, int world, int periodic_z, const void *unique_id, int device, void **comm)
 {
   try {
-    *comm = new pion_host::slab_comm_rccl(rank, world, periodic_z != 0, unique_id, device);
+    *comm = static_cast<pion_host::slab_comm *>(new pion_host::slab_comm_rccl(rank, world, periodic_z != 0, unique_id, device));
     return 0;
   }
   catch (const std::exception &e) {
@@ -173,17 +173,17 @@ int pion_host_comm_create(int rank, int world, int periodic_z, const void *uniqu
     return PION_GPU_EDEVICE;
   }
 }
-void pion_host_comm_destroy(void *c) { delete static_cast<pion_host::slab_comm_rccl *>(c); }
-int pion_host_comm_attach(void *c, void *gpu_handle) { return static_cast<pion_host::slab_comm_rccl *>(c)->attach(gpu_handle); }
-int pion_host_comm_start(void *c, int which) { return static_cast<pion_host::slab_comm_rccl *>(c)->start(which); }
-int pion_host_comm_finish(void *c) { return static_cast<pion_host::slab_comm_rccl *>(c)->finish(); }
+void pion_host_comm_destroy(void *c) { delete static_cast<pion_host::slab_comm *>(c); }
+int pion_host_comm_attach(void *c, void *gpu_handle) { return static_cast<pion_host::slab_comm *>(c)->attach(gpu_handle); }
+int pion_host_comm_start(void *c, int which) { return static_cast<pion_host::slab_comm *>(c)->start(which); }
+int pion_host_comm_finish(void *c) { return static_cast<pion_host::slab_comm *>(c)->finish(); }
 int pion_host_comm_allreduce_min(void *c, double *t_dyn, double *t_mp)
 {
-  return static_cast<pion_host::slab_comm_rccl *>(c)->allreduce_min(t_dyn, t_mp);
+  return static_cast<pion_host::slab_comm *>(c)->allreduce_min(t_dyn, t_mp);
 }
 int pion_host_comm_last_error(void *c, char *buf, int len)
 {
-  snprintf(buf, (size_t)len, "%s", static_cast<pion_host::slab_comm_rccl *>(c)->last_error().c_str());
+  snprintf(buf, (size_t)len, "%s", static_cast<pion_host::slab_comm *>(c)->last_error().c_str());
   return 0;
 }
 }

@@ -20,39 +20,40 @@
 #include <string>
 
 #include "../../include/pion_gpu.h"
+#include "slab_comm.h"
 
 namespace pion_host {
 
-class slab_comm_rccl {
+class slab_comm_rccl : public slab_comm {
  public:
   // unique_id: the 128 bytes of an ncclUniqueId made by rank 0 (get_unique_id) and handed to every
   // rank by the launcher.  periodic_z: the global z faces are periodic (rank 0 <-> world-1 exchange).
   // world == 1 with periodic_z is the loop-back case: the rank is its own neighbour (RCCL send/recv to
   // self), which reproduces the single-domain periodic run bit for bit.
   slab_comm_rccl(int rank, int world, bool periodic_z, const void *unique_id, int device);
-  ~slab_comm_rccl();
+  ~slab_comm_rccl() override;
   slab_comm_rccl(const slab_comm_rccl &) = delete;
 
   static int get_unique_id(void *out128);
 
   // create the communication stream and register it (pion_gpu_set_comm_stream); must precede start()
-  int attach(void *gpu_handle);
+  int attach(void *gpu_handle) override;
   // BC_update_BCMPI, first half: pack the on-grid planes next to the internal z faces of array `which`
   // (0 = P, 1 = Ph) and enqueue the grouped send / recv.  Returns at once.
-  int start(int which);
+  int start(int which) override;
   // second half: unpack into the ghost planes (communication stream; the library orders the
   // z-boundary part of the next stage after it)
-  int finish();
+  int finish() override;
   // global minimum of the device-resident {t_dyn, t_mp}: request_min() enqueues the all-reduce and the copy
   // to pinned host memory and returns (call it right after the full-step stage); allreduce_min() waits for
   // it (requesting first if nobody has) -- the single host synchronisation of a step
-  int request_min();
-  int allreduce_min(double *t_dyn, double *t_mp);
+  int request_min() override;
+  int allreduce_min(double *t_dyn, double *t_mp) override;
   // new state uploaded (sim_control_gpu::Init): complete an exchange in flight, forget a pending request_min()
-  int reset();
+  int reset() override;
 
   bool has_neighbours() const { return up_ >= 0 || down_ >= 0; }
-  const std::string &last_error() const { return err_; }
+  const std::string &last_error() const override { return err_; }
 
  private:
   int rank_, world_, device_, up_, down_;

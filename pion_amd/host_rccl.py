@@ -32,6 +32,8 @@ def load_host_library():
     C.CDLL(abi.library_path(), mode=C.RTLD_GLOBAL)
     h = C.CDLL(path)
     h.pion_host_sim_create.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.POINTER(C.c_void_p)]
+    h.pion_host_sim_create_backend.argtypes = [C.POINTER(abi.PionGpuConfig), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    h.pion_host_comm_shm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p)]
     h.pion_host_sim_destroy.argtypes = [C.c_void_p]
     h.pion_host_sim_destroy.restype = None
     h.pion_host_sim_handle.argtypes = [C.c_void_p]
@@ -61,16 +63,29 @@ def new_unique_id():
 
 
 class HostSim:
-    """pion_host::sim_control_gpu, optionally with a pion_host::slab_comm_rccl"""
+    """pion_host::sim_control_gpu, optionally with a slab communicator: pion_host::slab_comm_rccl (unique_id: the
+    128-byte ncclUniqueId) or pion_host::slab_comm_shm (shm_name: POSIX shared-memory name common to the ranks,
+    "/name" -- the host-staged transport).  backend: address of a pion_backend table (pion_amd/host/pion_backend.h);
+    None = libpion_gpu.so, the product's only backend (tests hand in the oracle's)."""
 
-    def __init__(self, cfg, device=0, rank=0, world=1, periodic_z=True, unique_id=None):
+    def __init__(self, cfg, device=0, rank=0, world=1, periodic_z=True, unique_id=None, shm_name=None, backend=None):
         self.lib = load_host_library()
         self.cfg = cfg
         self.s = C.c_void_p()
         self.comm = C.c_void_p()
-        if self.lib.pion_host_sim_create(C.byref(cfg), device, C.byref(self.s)) != 0:
+        if self.lib.pion_host_sim_create_backend(C.byref(cfg), device, backend, C.byref(self.s)) != 0:
             raise RuntimeError("pion_host_sim_create failed: " + self.last_error())
-        if unique_id is not None:
+        if shm_name is not None:
+            rc = self.lib.pion_host_comm_shm_create(rank, world, 1 if periodic_z else 0, shm_name.encode(), backend,
+                                                    C.byref(self.comm))
+            if rc != 0:
+                self.close()
+                raise RuntimeError("pion_host_comm_shm_create failed rc=%d" % rc)
+            rc = self.lib.pion_host_sim_set_comm(self.s, self.comm)
+            if rc != 0:
+                self.close()
+                raise RuntimeError("pion_host_sim_set_comm failed rc=%d" % rc)
+        elif unique_id is not None:
             idb = (C.c_char * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
             # RCCL prints a version banner on stdout when a communicator is created: send it to stderr
             # (bench.py's stdout carries exactly one JSON line)

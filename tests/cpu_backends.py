@@ -116,15 +116,20 @@ class RefCooling:
 class CpuSim:
     """One handle of the oracle ("orc") or of the reference harness ("ref")."""
 
-    def __init__(self, cfg, kind="orc"):
+    def __init__(self, cfg, kind="orc", borrowed_handle=None):
         self.kind = kind
         self.cfg = cfg
         self.lib = C.CDLL(ORACLE_SO if kind == "orc" else REF_SO)
         self.pre = kind + "_"
         self.h = C.c_void_p()
-        rc = self._f("create")(C.byref(cfg), C.byref(self.h))
-        if rc != 0:
-            raise RuntimeError("create failed %d" % rc)
+        self.borrowed = borrowed_handle is not None
+        if self.borrowed:
+            # an oracle handle owned by someone else (the test backend of the C++ host loop): set-up calls only
+            self.h = C.c_void_p(borrowed_handle)
+        else:
+            rc = self._f("create")(C.byref(cfg), C.byref(self.h))
+            if rc != 0:
+                raise RuntimeError("create failed %d" % rc)
         self.nvar = cfg.nvar
         self.ncell = abi.ncell_all(cfg)
         nga = abi.ng_all(cfg)
@@ -145,6 +150,8 @@ class CpuSim:
             raise RuntimeError("%s%s failed rc=%d %s" % (self.pre, what, rc, msg))
 
     def close(self):
+        if self.h and self.borrowed:
+            self.h = None
         if self.h:
             f = getattr(self.lib, self.pre + "destroy")
             f.restype = None
