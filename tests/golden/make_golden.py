@@ -213,8 +213,38 @@ def main_d():
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+def main_e():
+    """shocktubes.npz: the shock-tube initial conditions the reference ships (gc.SHOCK_TUBES: Toro 1-5, Brio-Wu,
+    Falle FS/SS/FR/SR/OFS, Ryu-Jones 1a-5b) run by the reference objects in 1-D to their finish times: every dt and
+    the end state.  One child process per case: the reference exits the process on a failed Riemann solve.
+    `make_golden.py e [case]`."""
+    import subprocess
+    if len(sys.argv) > 2:
+        name = sys.argv[2]
+        cfg, P, tf = gc.shock_tube_case(name)
+        with CpuSim(cfg, "ref") as r:
+            n, t, dts = gc.end_run(r, cfg, P, tf, 100000)
+            A = r.download(0)
+        np.savez(os.path.join("/tmp", "st_%s.npz" % name), n=n, t=t, dt=dts, P=A)
+        return
+    out = {}
+    for name in gc.SHOCK_TUBES:
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "e", name], stdout=subprocess.DEVNULL)
+        if rc != 0:
+            print("%-10s the reference gave up (exit %d): no fixture" % (name, rc))
+            continue
+        z = np.load(os.path.join("/tmp", "st_%s.npz" % name))
+        for k in ("n", "t", "dt", "P"):
+            out[name + "_" + k] = z[k]
+        print("%-10s %4d steps to t = %.6g" % (name, int(z["n"]), float(z["t"])))
+    np.savez_compressed(os.path.join(HERE, "shocktubes.npz"), **out)
+    print("shocktubes.npz", os.path.getsize(os.path.join(HERE, "shocktubes.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "d":
+    if len(sys.argv) > 1 and sys.argv[1] == "e":
+        main_e()
+    elif len(sys.argv) > 1 and sys.argv[1] == "d":
         main_d()
     elif len(sys.argv) > 1 and sys.argv[1] == "b":
         main_b()
@@ -225,3 +255,4 @@ if __name__ == "__main__":
         main_b()
         main_c()
         main_d()
+        main_e()

@@ -364,3 +364,61 @@ def end_case_c(name, strict_fp=1):
         cfg, P = problems.cooling_blast3d(20, strict_fp=strict_fp)
         return cfg, P, 1.0e30, 60
     raise KeyError(name)
+
+
+# ---- the shock tubes the reference ships as initial conditions (shocktubes.npz, `make_golden.py e`) -------------
+# Left / right states, interface position, gamma and finish time of IC_shocktube::get_riemann_ics
+# (source/ics/shock_tube.cpp:473-815; the same table in dataIO/dataio_text.cpp:734-1080): Toro's tests 1-5
+# (:477-530), Brio & Wu and Falle's FS / SS / FR / SR / OFS (:546-652), Ryu & Jones 1a-5b (:657-815; the reference
+# sets no finish time for those: the times of Ryu & Jones 1995, ApJ 442, 228, figs 1-5 are used).  Run set-up of
+# test_problems/untested/test_ShockTubes/pf_st_toro*.txt (Euler, hybrid solver 3, CFL 0.7, FKJ98 viscosity eta 0.3)
+# and pf_st_falle*.txt (ideal MHD, HLLD, CFL 0.7, no artificial viscosity): 1-D, 200 cells on [0, 1], outflow.
+_S4PI = 1.0 / np.sqrt(4.0 * np.pi)
+# name: (gamma, xm, finishtime, left, right); states as (rho, p, vx, vy, vz[, Bx, By, Bz])
+SHOCK_TUBES_HD = {
+    "toro1": (1.4, 0.3, 0.2, (1.0, 1.0, 0.75, 0.0, 0.0), (0.125, 0.1, 0.0, 0.0, 0.0)),
+    "toro2": (1.4, 0.5, 0.15, (1.0, 0.4, -2.0, 0.0, 0.0), (1.0, 0.4, 2.0, 0.0, 0.0)),
+    "toro3": (1.4, 0.5, 0.012, (1.0, 1000.0, 0.0, 0.0, 0.0), (1.0, 0.01, 0.0, 0.0, 0.0)),
+    "toro4": (1.4, 0.4, 0.035, (5.99924, 460.894, 19.5975, 0.0, 0.0), (5.99242, 46.0950, -6.19633, 0.0, 0.0)),
+    "toro5": (1.4, 0.8, 0.012, (1.0, 1000.0, -19.59745, 0.0, 0.0), (1.0, 0.01, -19.59745, 0.0, 0.0)),
+}
+SHOCK_TUBES_MHD = {
+    "falle_bw": (2.0, 0.5, 0.12, (1.0, 1.0, 0.0, 0.0, 0.0, 0.75, 1.0, 0.0), (0.125, 0.1, 0.0, 0.0, 0.0, 0.75, -1.0, 0.0)),
+    "falle_fs": (5.0 / 3.0, 0.3, 0.4, (3.0, 16.33, -0.732, -1.333, 0.0, 3.0, 2.309, 0.0), (1.0, 1.0, -4.196, 0.0, 0.0, 3.0, 0.0, 0.0)),
+    "falle_ss": (5.0 / 3.0, 0.3, 0.5, (1.368, 1.769, 0.269, 1.0, 0.0, 1.0, 0.0, 0.0), (1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0)),
+    "falle_fr": (5.0 / 3.0, 0.5, 0.1, (1.0, 2.0, 0.0, 0.0, 0.0, 1.0, 3.0, 0.0), (0.2641, 0.2175, 3.6, -2.551, 0.0, 1.0, 0.0, 0.0)),
+    "falle_sr": (5.0 / 3.0, 0.5, 0.3, (1.0, 2.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0), (0.2, 0.1368, 1.186, 2.967, 0.0, 1.0, 1.6405, 0.0)),
+    "falle_ofs": (5.0 / 3.0, 0.5, 0.15, (1.0, 1.0, 6.505, 1.0, 0.0, 1.0, 1.0, 1.0), (3.0, 20.268, 2.169, 1.331, 0.331, 1.0, 3.153, 3.153)),
+    "rj1a": (5.0 / 3.0, 0.5, 0.08, (1.0, 20.0, 10.0, 0.0, 0.0, 5 * _S4PI, 5 * _S4PI, 0.0), (1.0, 1.0, -10.0, 0.0, 0.0, 5 * _S4PI, 5 * _S4PI, 0.0)),
+    "rj1b": (5.0 / 3.0, 0.5, 0.03, (1.0, 1.0, 0.0, 0.0, 0.0, 3 * _S4PI, 5 * _S4PI, 0.0), (0.1, 10.0, 0.0, 0.0, 0.0, 3 * _S4PI, 2 * _S4PI, 0.0)),
+    "rj2a": (5.0 / 3.0, 0.5, 0.2, (1.08, 0.95, 1.2, 0.01, 0.5, 2 * _S4PI, 3.6 * _S4PI, 2 * _S4PI), (1.0, 1.0, 0.0, 0.0, 0.0, 2 * _S4PI, 4 * _S4PI, 2 * _S4PI)),
+    "rj2b": (5.0 / 3.0, 0.5, 0.035, (1.0, 1.0, 0.0, 0.0, 0.0, 3 * _S4PI, 6 * _S4PI, 0.0), (0.1, 10.0, 0.0, 2.0, 1.0, 3 * _S4PI, 1 * _S4PI, 0.0)),
+    "rj3a": (5.0 / 3.0, 0.5, 0.01, (0.1, 0.4, 50.0, 0.0, 0.0, 0.0, -1 * _S4PI, -2 * _S4PI), (0.1, 0.2, 0.0, 0.0, 0.0, 0.0, 1 * _S4PI, 2 * _S4PI)),
+    "rj3b": (5.0 / 3.0, 0.5, 0.1, (1.0, 1.0, -1.0, 0.0, 0.0, 0.0, 1.0, 0.0), (1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0)),
+    "rj4a": (5.0 / 3.0, 0.5, 0.15, (1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 0.0), (0.2, 0.1, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0)),
+    "rj4b": (5.0 / 3.0, 0.5, 0.15, (0.4, 0.52467, -0.66991, 0.98263, 0.0, 1.3, 0.0025293, 0.0), (1.0, 1.0, 0.0, 0.0, 0.0, 1.3, 1.0, 0.0)),
+    "rj4c": (5.0 / 3.0, 0.5, 0.15, (0.65, 0.5, 0.667, -0.257, 0.0, 0.75, 0.55, 0.0), (1.0, 0.75, 0.4, -0.94, 0.0, 0.75, 0.0, 0.0)),
+    "rj4d": (5.0 / 3.0, 0.5, 0.16, (1.0, 1.0, 0.0, 0.0, 0.0, 0.7, 0.0, 0.0), (0.3, 0.2, 0.0, 0.0, 1.0, 0.7, 1.0, 0.0)),
+    "rj5a": (5.0 / 3.0, 0.5, 0.1, (1.0, 1.0, 0.0, 0.0, 0.0, 0.75, 1.0, 0.0), (0.125, 0.1, 0.0, 0.0, 0.0, 0.75, -1.0, 0.0)),
+    "rj5b": (5.0 / 3.0, 0.5, 0.16, (1.0, 1.0, 0.0, 0.0, 0.0, 1.3, 1.0, 0.0), (0.4, 0.4, 0.0, 0.0, 0.0, 1.3, -1.0, 0.0)),
+}
+SHOCK_TUBES = list(SHOCK_TUBES_HD) + list(SHOCK_TUBES_MHD)
+
+
+def shock_tube_case(name, strict_fp=1, nx=200):
+    """-> (cfg, P, finishtime)"""
+    if name in SHOCK_TUBES_HD:
+        gam, xm, tf, L, R = SHOCK_TUBES_HD[name]
+        cfg = abi.make_config(1, [nx], abi.EQEUL, abi.FLUX_RShybrid, artvisc=abi.AV_FKJ98_1D, etav=0.3, gamma=gam,
+                              cfl=0.7, xmin=(0.0, 0.0, 0.0), xmax=(1.0, 0.0, 0.0), bcs=["outflow", "outflow"],
+                              refvec=[1.0] * 5, strict_fp=strict_fp)
+    else:
+        gam, xm, tf, L, R = SHOCK_TUBES_MHD[name]
+        cfg = abi.make_config(1, [nx], abi.EQMHD, abi.FLUX_RS_HLLD, artvisc=0, etav=0.15, gamma=gam,
+                              cfl=0.7, xmin=(0.0, 0.0, 0.0), xmax=(1.0, 0.0, 0.0), bcs=["outflow", "outflow"],
+                              refvec=[1.0] * 8, strict_fp=strict_fp)
+    P = problems.alloc(cfg)
+    X, _, _ = problems.mesh(cfg)
+    for v in range(cfg.nvar):
+        P[v] = np.where(X < xm, L[v], R[v])
+    return cfg, P, tf
