@@ -153,17 +153,21 @@ def cpu_baseline(n, eqn, budget_s=10.0):
     res_all = _run_cpu_workers(["%s,m1,%s,%d,%d,%d,%g" % (kind, eqn, n, n, n // C, budget_s)] * C)
     if any(r is None for r in res_all):
         return None
-    singles = _run_cpu_workers(["%s,m1,%s,%d,%d,%d,%g" % (kind, eqn, n, n, n, budget_s),
-                                "orc,m1,%s,%d,%d,%d,%g" % (eqn, n, n, n, budget_s),
+    ns = min(n, 128)   # the single-process samples stay at 128^3 (6 s per step; 256^3 would take a minute per step)
+    singles = _run_cpu_workers(["%s,m1,%s,%d,%d,%d,%g" % (kind, eqn, ns, ns, ns, budget_s),
+                                "orc,m1,%s,%d,%d,%d,%g" % (eqn, ns, ns, ns, budget_s),
                                 "%s,m2,%s,48,48,48,%g" % (kind, eqn, 0.6 * budget_s),
                                 "orc,m3,%s,48,48,48,%g" % (eqn, 0.6 * budget_s)])
     lib = "oracle/_ref/libpion_ref.so (reference objects, -O3 -DSERIAL)" if kind == "ref" else "oracle/liboracle.so"
     out = {"value": sum(rate(r) for r in res_all), "unit": "Mcell-updates/s", "cores": C,
            "kind": "reference" if kind == "ref" else "port",
-           "sample": "M1 (GLM-MHD HLLD blast) %d^3 as %d independent periodic z-slabs %dx%dx%d, one process per core, "
-                     "%d-%d steps each in %.0f s; %s; host has %d cores available" % (
-                         n, C, n, n, n // C, min(r["steps"] for r in res_all), max(r["steps"] for r in res_all),
-                         max(r["seconds"] for r in res_all), lib, cores)}
+           "sample": "M1 (GLM-MHD HLLD blast) %d^3 as %d independent periodic z-slabs %dx%dx%d (each computes %d planes "
+                     "with its ghosts for %d counted: %.0f %% overhead of the decomposition), one process per core, "
+                     "%d-%d steps each in %.0f s; %s; host has %d cores available; single_core_value / port_value: "
+                     "%d^3 in one process" % (
+                         n, C, n, n, n // C, n // C + 4, n // C, 400.0 / (n // C),
+                         min(r["steps"] for r in res_all), max(r["steps"] for r in res_all),
+                         max(r["seconds"] for r in res_all), lib, cores, ns)}
     if singles[0]:
         out["single_core_value"] = rate(singles[0])
     if singles[1]:
@@ -185,6 +189,10 @@ def parity_build_run(args, cfg, device, dt_lim, steps=3, warmup=1):
             P = problems.fill_mhd_blastwave(cfg)
         elif args.workload == "m2":
             P = problems.fill_hd_blast_octant(cfg, args.n / 32.0)
+        elif args.workload == "dmr2d":
+            _, P = problems.double_mach_reflection(args.n, strict_fp=1)
+        elif args.workload == "mhd2d":
+            P = problems.fill_mhd_blastwave(cfg)
         else:
             from pion_amd import cooling
             P, (widx, wst), dt_lim = problems.fill_wind3d(cfg, args.n)
@@ -242,20 +250,26 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the launches with HIP events (A/B of the event overhead; roofline fields are 0)")
     ap.add_argument("--no-parity-build", action="store_true", help="skip the strict-build throughput run")
-    ap.add_argument("--cpu-n", type=int, default=128, help="cells per axis of the CPU baseline sample")
-    ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3"],
+    ap.add_argument("--cpu-n", type=int, default=256,
+                    help="cells per axis of the all-cores CPU baseline sample (16 slabs of n x n x n/16; the single-process "
+                         "samples use min(n, 128))")
+    ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3", "dmr2d", "mhd2d"],
                     help="m1 (default, the headline): MHD blast; m2: 3-D Euler Roe-CV octant Sedov blast (SURVEY 8d); "
-                         "m3: Wind3D single level, FVS + cooling 8 + stellar wind (single GPU).  m2/m3 are extra rows for "
+                         "m3: Wind3D single level, FVS + cooling 8 + stellar wind (single GPU); dmr2d / mhd2d: BASELINE "
+                         "configs 2 and 3 (2-D double Mach reflection, Euler Roe-CV, --grid = cells along x, ny = nx / 3.25; "
+                         "2-D GLM-MHD blast wave, HLLD, --grid = nx, ny = 1.5 nx), one GPU.  All but m1 are extra rows for "
                          "DESIGN.md")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
                          "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
-    ap.add_argument("--transport", default="host", choices=["host", "torch"],
+    ap.add_argument("--transport", default="host", choices=["host", "shm", "torch"],
                     help="who drives the time loop and the N>1 transport: host (default) = the C++ host layer "
                          "(pion_host::sim_control_gpu + slab_comm_rccl: RCCL send/recv groups and the dt all-reduce "
                          "issued from C++; torch.distributed/gloo only broadcasts the ncclUniqueId and hosts the "
-                         "timing barrier); torch = the Python driver with torch.distributed P2P (round-1 path; "
-                         "required for --backend gloo)")
+                         "timing barrier); shm = the same C++ time loop with pion_host::slab_comm_shm (halo planes staged "
+                         "through pinned host buffers and POSIX shared memory: no RCCL; ranks may share a GPU; the fall-back "
+                         "when no RCCL communicator can be made); torch = the Python driver with torch.distributed P2P "
+                         "(round-1 path; required for --backend gloo)")
     ap.add_argument("--nz", type=int, default=0,
                     help="m1 only: cells along z if not --n (with --loopback and nz = n/N this is exactly the slab, the "
                          "launches and the transfers of one rank of an N-rank run)")
@@ -290,12 +304,13 @@ def main():
 
     comm = None
     torch = None
-    use_host = (args.transport == "host" and args.backend == "nccl")
+    use_host = (args.transport in ("host", "shm") and args.backend == "nccl")
+    use_shm = (args.transport == "shm")
     if world > 1 and use_host:
         import torch
         import torch.distributed as dist
         with _stdout_to_stderr():
-            dist.init_process_group("gloo")   # bootstrap (ncclUniqueId) and timing barrier only
+            dist.init_process_group("gloo")   # bootstrap (ncclUniqueId / segment name) and timing barrier only
             dist.barrier()
     elif world > 1:
         import torch
@@ -324,11 +339,25 @@ def main():
     periodic_z = True
     hs = None
 
+    transport_note = []
+
     def make_sim(cfg, periodic_z):
-        """the handle the benchmark drives: owned by the C++ host layer (transport host) or by Python"""
+        """the handle the benchmark drives: owned by the C++ host layer (transport host / shm) or by Python"""
         if not use_host:
             return None, lib.GpuSim(cfg, local_rank)
         from pion_amd import host_rccl
+        ngpu = 1
+        if world > 1:
+            import torch
+            ngpu = max(1, torch.cuda.device_count())
+        dev = local_rank % ngpu
+        if world > 1 and (use_shm or ngpu < world):
+            # host-staged transport: ranks agree on a shared-memory name through the bootstrap group
+            box = ["/pion_bench_%d" % os.getpid() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            transport_note.append("shm")
+            h = host_rccl.HostSim(cfg, dev, rank=rank, world=world, periodic_z=periodic_z, shm_name=box[0])
+            return h, lib.GpuSim(cfg, borrowed_handle=h.gpu_handle())
         uid = None
         if world > 1:
             box = [host_rccl.new_unique_id() if rank == 0 else None]
@@ -336,7 +365,25 @@ def main():
             uid = box[0]
         elif loopback:
             uid = host_rccl.new_unique_id()
-        h = host_rccl.HostSim(cfg, local_rank, rank=rank, world=world, periodic_z=periodic_z, unique_id=uid)
+        try:
+            h = host_rccl.HostSim(cfg, dev, rank=rank, world=world, periodic_z=periodic_z, unique_id=uid)
+            ok = 1
+        except RuntimeError as e:
+            sys.stderr.write("bench.py rank %d: RCCL communicator failed (%s)\n" % (rank, e))
+            h, ok = None, 0
+        if world > 1:
+            # every rank must take the same transport: fall back to the host-staged one if ANY rank failed
+            oks = [None] * world
+            dist.all_gather_object(oks, ok)
+            if not all(oks):
+                if h is not None:
+                    h.close()
+                box = ["/pion_bench_%d" % os.getpid() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                transport_note.append("shm (fall-back: no RCCL communicator)")
+                h = host_rccl.HostSim(cfg, dev, rank=rank, world=world, periodic_z=periodic_z, shm_name=box[0])
+        elif h is None:
+            raise SystemExit("bench.py: RCCL loop-back communicator failed")
         return h, lib.GpuSim(cfg, borrowed_handle=h.gpu_handle())
 
     if args.workload == "m1":
@@ -359,6 +406,25 @@ def main():
         cfg = slab.slab_config(cfg_g, rank, world)
         P = problems.fill_hd_blast_octant(cfg, n / 32.0)
         wl_name = "M2: 3-D Euler octant Sedov blast %d^3, Roe-CV + FKJ98 0.1, reflecting/outflow, OA2/OA2" % n
+        periodic_z = False
+        hs, sim = make_sim(cfg, False)
+        eq = cfg.eqntype
+    elif args.workload in ("dmr2d", "mhd2d"):
+        # BASELINE configs[1] / [2] on one GPU (2-D grids do not shard along z)
+        if world > 1:
+            raise SystemExit("bench.py: the 2-D workloads run on one GPU")
+        if args.workload == "dmr2d":
+            cfg, P = problems.double_mach_reflection(n, strict_fp=args.strict)
+            wl_name = ("DMR2D: double Mach reflection %d x %d, Euler Roe-CV + FKJ98 0.1, inflow/outflow/reflecting/DMR, "
+                       "OA2/OA2" % (cfg.ng[0], cfg.ng[1]))
+        else:
+            cfg, _ = problems.mhd_blastwave(4, 2, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=args.strict)
+            cfg.ng[0], cfg.ng[1] = n, (3 * n) // 2
+            cfg.dx = 1.0 / n
+            cfg.xmin[1] = -0.75
+            P = problems.fill_mhd_blastwave(cfg)
+            wl_name = "MHD2D: GLM-MHD Stone blast wave %d x %d, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2" % (cfg.ng[0], cfg.ng[1])
+        cfg_g = cfg
         periodic_z = False
         hs, sim = make_sim(cfg, False)
         eq = cfg.eqntype
@@ -484,7 +550,7 @@ def main():
             "config": {"workload": wl_name or "M1: 3-D %s Stone blast wave %d^3, HLLD + FKJ98 eta 0.1, periodic, OA2/OA2"
                                    % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
                        "grid": [int(v) for v in cfg_g.ng[:3]], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": ("RCCL send/recv to self (loopback)" if loopback else "none" if world == 1 else
-                                     ("RCCL P2P" if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"))
+                                     ((transport_note[0] + ": pinned host buffers + POSIX shared memory" if transport_note else "RCCL P2P") if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"))
                        + ("; time loop and transport issued from C++ (libpion_host)" if hs is not None else "; Python driver"),
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -494,7 +560,8 @@ def main():
                                            "prepass, boundary and reduction launches included",
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r02_pmc_traffic.json; null when the kernel sources have changed since)",
                          "kernel": {"m1": "k_stage_rows2<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows2<MHD,0,HLLD>",
-                                    "m2": "k_stage_rows2<EUL,0,Roe-CV>", "m3": "k_stage_rows2<EUL,1,FVS>"}[args.workload]
+                                    "m2": "k_stage_rows2<EUL,0,Roe-CV>", "m3": "k_stage_rows2<EUL,1,FVS>",
+                                    "dmr2d": "2-D stage kernel <EUL,0,Roe-CV>", "mhd2d": "2-D stage kernel <GLM,0,HLLD>"}[args.workload]
                                    + " (first-order + second-order instance, mean per launch)",
                          "kernel_ms": stage_ms, "kernel_ms_from": "HIP events over %d steps after the timed region" % ev_steps, "launches_per_stage": (tm["stage_n"] / (2.0 * ev_steps) if ev_steps else 0.0), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes, "issue": valu},

@@ -38,6 +38,7 @@ struct CoolDev {
   double MinT_allowed, MaxT_allowed;
 };
 
+#define PION_MAX_ZCHUNKS 47
 struct StageArgs {
   GridDesc g;
   const double *S;    // stencil state ("Ph")      [nvar][ncell]
@@ -59,6 +60,10 @@ struct StageArgs {
   int zslope_lds;     // k_stage_rows2: carry the z slope in LDS (else rebuild it from plane k-1)
   double *dE;         // k_stage_rows2: cooling source PtoU(p_new)[ERG]-PtoU(P)[ERG] per cell from k_cooling_dE (or null)
   int zchunk;         // planes per wavefront in the marching kernels
+  // k_stage_rows2, first strip [kz0,kz1): nzb > 0 = uneven chunks, chunk i covers planes kz0 + zb[i] .. kz0 + zb[i+1]
+  // (long chunks first, short ones last: the launch's last wavefronts are short, so its tail is)
+  int nzb;
+  short zb[PION_MAX_ZCHUNKS + 1];
   int rows;           // y-rows per wavefront in k_stage_rows2
   int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows2; k_stage: whole grid)
   int kz2, kz3;       // and a second strip [kz2,kz3) (empty when kz3 <= kz2): the two z-boundary strips

@@ -471,6 +471,7 @@ struct Handle {
   int zslope_lds = 1;     // k_stage_rows2: carry the z slope in LDS (default; PION_ZSLOPE_LDS=0: rebuild it from plane k-1, R = 4)
   double *ddE = nullptr;  // cooling source per cell (k_cooling_dE -> k_stage_rows2)
   bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
+  bool uneven_chunks = true;   // PION_UNEVEN_CHUNKS=0: equal plane chunks (A/B)
   bool fuse_bc = true;    // PION_FUSE_BC=0: periodic faces one launch per face (A/B)
 };
 
@@ -612,7 +613,8 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (const char *e = getenv("PION_CONCURRENT_STRIPS")) h->concurrent_strips = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
-  if (const char *e = getenv("PION_ROWS")) h->rows = h->rows1 = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
+  if (const char *e = getenv("PION_UNEVEN_CHUNKS")) h->uneven_chunks = (atoi(e) != 0);
+  if (const char *e = getenv("PION_ROWS")) h->rows = h->rows1 = (atoi(e) >= 1 && atoi(e) <= 64) ? atoi(e) : 0;
   if (const char *e = getenv("PION_ROWS1")) h->rows1 = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
   if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 0;
   h->device = device;
@@ -642,7 +644,11 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   *handle = h;
   // k_stage_rows2 (3-D, two ghost layers) addresses every array as "uniform base + 32-bit byte offset of the
   // cell": grids of 2^29 cells or more (ghosts included) use the cell-per-thread kernel with 64-bit addresses
-  if (!(g.ndim == 3 && g.nbc[2] >= 2 && (unsigned long long)g.ncell * 8ull < (1ull << 32))) h->use_march = 0;
+  // (2-D Cartesian grids run it without the z part; PION_ROWS_2D=0 puts them back on the cell-per-thread kernel)
+  const bool rows3d = (g.ndim == 3 && g.nbc[2] >= 2);
+  bool rows2d = (g.ndim == 2 && g.cyl == 0 && g.nbc[1] >= 2 && g.nbc[0] >= 2);
+  if (const char *e = getenv("PION_ROWS_2D")) rows2d = rows2d && (atoi(e) != 0);
+  if (!((rows3d || rows2d) && (unsigned long long)g.ncell * 8ull < (1ull << 32))) h->use_march = 0;
 
   const size_t nb = sizeof(double) * (size_t)cfg->nvar * g.ncell;
   HCHECK(h, hipMalloc(&h->dP, nb));
@@ -1251,7 +1257,7 @@ int pion_gpu_set_glm_speeds(void *handle, double dt, double dx, double cr)
 // part (the nbc on-grid planes next to each z face) waits for the unpacked halo.
 static bool stage_can_split(const Handle *h)
 {
-  return h->use_march != 0 && !h->deta
+  return h->use_march != 0 && !h->deta && h->g.ndim == 3
          && h->g.ng[2] > 2 * h->g.nbc[2] && !(h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1);
 }
 
@@ -1356,7 +1362,13 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   // periodic x: k_stage_rows2 writes the x ghost images of its rows (the boundary launch then skips them)
   a.xwrap = (a.use_march != 0 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC
              && cfg.bc_type[1] == PION_BC_PERIODIC && h->g.ng[0] >= 2 * h->g.nbc[0]) ? 1 : 0;
-  if (a.use_march != 0)
+  if (a.use_march != 0 && h->g.ndim == 2) {
+    // 2-D: rows per wavefront marched along y (nothing in LDS): 2 + 1/R solves per cell against the number of
+    // wavefronts; 8 keeps >= 4 rounds of wavefronts on grids from 2048 x 512 up (PION_ROWS overrides)
+    a.rows = (h->rows > 0) ? h->rows : 8;
+    if (a.rows > 64) a.rows = 64;
+  }
+  else if (a.use_march != 0)
     a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, space_ooa == 2 ? h->rows : h->rows1)
                            : fp_fast::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, space_ooa == 2 ? h->rows : h->rows1);
   if (a.zchunk <= 0) {
@@ -1388,6 +1400,26 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
       }
     }
   }
+  // Uneven chunks (default; PION_UNEVEN_CHUNKS=0: equal chunks of a.zchunk planes): chunks of the model's length
+  // while more than two of them remain, then halving down to 4 planes.  Wavefronts are dispatched in chunk order, so
+  // the last ones to start are the shortest and the launch ends with (nearly) all slots busy; a priming plane costs
+  // about a third of a plane visit (its z task only).  512 planes: 14 x 32, 32, 16, 8, 4, 4; a 64-plane slab:
+  // 32, 16, 8, 4, 4 (equal chunks: 3.25 ms/step for 512 x 512 x 64, 88 % of the per-cell rate of 512^3).
+  a.nzb = 0;
+  if (a.use_march != 0 && h->uneven_chunks && kz1 - kz0 >= 16) {
+    const int np = kz1 - kz0, cmax = (h->zchunk > 0) ? h->zchunk : 32;
+    int n = 0, pos = 0;
+    a.zb[0] = 0;
+    while (pos < np && n < PION_MAX_ZCHUNKS) {
+      const int rem = np - pos;
+      int c = (rem > 2 * cmax) ? cmax : ((rem / 2 > 4) ? rem / 2 : 4);
+      if (c > cmax) c = cmax;
+      if (c > rem || rem - c < 3) c = rem;
+      pos += c;
+      a.zb[++n] = (short)pos;
+    }
+    if (pos == np) a.nzb = n;
+  }
   if (cfg.cooling != 0 && a.use_march != 0) {
     // calc_noRT_microphysics_dU as its own launch (thread per cell, full occupancy): dE per cell
     a.dE = h->ddE;
@@ -1401,8 +1433,8 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   }
   // fused time-step reduction: the full stage leaves min(t_dyn), min(t_mp) of the new state in ddt
   // (second-order stages only: the first-order instances of k_stage_rows2 carry no reduction code)
-  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march != 0 && h->g.ndim == 3
-                       && h->g.nbc[2] >= 2 && a.out == h->dP;
+  const bool fuse_dt = h->fuse_dt && is_full_step && space_ooa == 2 && a.use_march != 0
+                       && ((h->g.ndim == 3 && h->g.nbc[2] >= 2) || h->g.ndim == 2) && a.out == h->dP;
   a.dtres = nullptr;
   a.cfl = cfg.cfl;
   a.dt_mp = mp_dt_limited(cfg) ? 1 : 0;

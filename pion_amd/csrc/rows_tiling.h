@@ -1,4 +1,4 @@
-// stage_rows.h -- x/y tiling of one plane chunk of the 3-D stage kernel (k_stage_rows2, stage_rows2.h),
+// rows_tiling.h -- x/y tiling of one plane chunk of the 3-D stage kernel (k_stage_rows2, stage_rows2.h),
 // shared by the kernel and its launcher.
 //
 // x: full tiles of PION_MARCH_XT = 62 cells, one wavefront each (lanes 0 and 63 are halo lanes that only
@@ -6,8 +6,8 @@
 // of a wavefront idle, so a "remainder" wavefront packs the remainders of `spw` consecutive row groups side by
 // side, each in a segment of rem + 2 lanes with its own two halo lanes (the x shuffles only ever cross a segment
 // boundary into a halo lane).  y: groups of a.rows consecutive rows per wavefront.
-#ifndef PION_STAGE_ROWS_H
-#define PION_STAGE_ROWS_H
+#ifndef PION_ROWS_TILING_H
+#define PION_ROWS_TILING_H
 
 // x/y tiling of one plane chunk, shared by the kernel and its launcher
 struct RowsTiling {

@@ -1,12 +1,12 @@
-// stage_march.h -- helpers shared by the 3-D stage kernel (stage_rows2.h): sweep-frame loads, slopes, the
+// stage_helpers.h -- helpers shared by the 3-D stage kernel (stage_rows2.h): sweep-frame loads, slopes, the
 // per-axis source + flux-difference update, CellAdvanceTime, CellTimeStep, the wavefront minimum.
 //
 // Included by kernels_fp.hip inside namespace pion::PION_FPNS.  (The round-1 kernels k_stage_march -- one
 // row per wavefront, z carry in registers, 4 Riemann solves per cell -- and k_stage_rows -- R = 4 rows per
-// wavefront at one wavefront per SIMD, 500 registers -- lived here and in stage_rows.h; k_stage_rows2
+// wavefront at one wavefront per SIMD, 500 registers -- lived in this file (then stage_march.h) and in stage_rows.h (now rows_tiling.h); k_stage_rows2
 // superseded both, DESIGN.md s4 keeps their measurements.)
-#ifndef PION_STAGE_MARCH_H
-#define PION_STAGE_MARCH_H
+#ifndef PION_STAGE_HELPERS_H
+#define PION_STAGE_HELPERS_H
 
 template <int NV, bool MHD>
 PDEV void load_rot(const double *S, const long nc, const int ax, const long c, double *q)

@@ -1,6 +1,6 @@
 // stage_rows2.h -- k_stage_rows2: the 3-D production stage kernel, two wavefronts per SIMD (MHD) or three (Euler).
 //
-// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after dev_addr.h, stage_march.h and stage_rows.h,
+// Included by kernels_fp.hip inside namespace pion::PION_FPNS (after dev_addr.h, stage_helpers.h and rows_tiling.h,
 // whose helpers uni / ldu / pin_v / opaque_zero, apply_axis / cell_update, rows_tiling it uses; cell_dt is
 // kernels_fp.hip's).
 //
@@ -93,8 +93,10 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #ifndef PION_ROWS2_YWG
 #define PION_ROWS2_YWG 1
 #endif
-#ifndef PION_ROWS2_UNROLL_T
-#define PION_ROWS2_UNROLL_T 0
+// PION_ROWS2_COPIES=1: the x, y and z tasks of a row as three straight-line copies of the task body; 0: one body in
+// a uniform task loop (A/B)
+#ifndef PION_ROWS2_COPIES
+#define PION_ROWS2_COPIES 1
 #endif
 #ifndef PION_ROWS2_U0
 #define PION_ROWS2_U0 1
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   const int R = a.rows;
   const RowsTiling tl = rows_tiling(a);
   const int nyg = tl.nyg;
-  const int nzc1 = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
+  const int nzc1 = (a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
   const int nzc = nzc1 + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;   // chunks of both strips
   const long ntiles = (long)tl.per_chunk * nzc;
   // the wavefront number is uniform: say so, and the tile / row / plane loops run on the scalar unit
@@ -156,9 +158,16 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   const int j0 = jg * R;
   const int nrows = (jg_first * R + R <= a.g.ng[1]) ? R : a.g.ng[1] - jg_first * R;
   const int nrows_l = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
-  const int k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
-  const int kend = (cz < nzc1) ? a.kz1 : a.kz3;
-  const int k1 = (k0 + a.zchunk < kend) ? k0 + a.zchunk : kend;
+  int k0, k1;
+  if (a.nzb > 0 && cz < nzc1) {
+    k0 = a.kz0 + a.zb[cz];
+    k1 = a.kz0 + a.zb[cz + 1];
+  }
+  else {
+    k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
+    const int kend = (cz < nzc1) ? a.kz1 : a.kz3;
+    k1 = (k0 + a.zchunk < kend) ? k0 + a.zchunk : kend;
+  }
 
   const long nc = a.g.ncell, sy = a.g.sy, sz = a.g.sz;
   const long ncb = nc * 8, syb = sy * 8, szb = sz * 8;   // byte strides (uniform)
@@ -166,6 +175,9 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   const char *const Hb = reinterpret_cast<const char *>(a.hllflag);
   const double g = a.fc.gamma, dx = a.g.dx, dt = a.dt;
   const bool oa2 = (OAMODE == 0) ? (a.space_ooa == 2) : (OAMODE == 2);
+  // 2-D Cartesian grids run the same kernel without its z part: one "plane", a group of R rows per wavefront marched
+  // along y with the flux and the slope carried in registers (2 + 1/R Riemann solves per cell), no LDS
+  const bool noz = (a.g.ndim == 2);
   const double thr = PION_VERY_TINY_VALUE * dx * dx;   // AvgFalle's zero test on raw differences (fast build)
   const bool hcorr = PLAIN ? false : (a.fc.artvisc == AV_HCORRECTION || a.fc.artvisc == AV_HCORR_FKJ98);
   // first-order stages read their stencil from the start-of-step array (time_integrator.cpp:151-250:
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
 
   // z state of the priming plane k0-1 for every row
 #pragma unroll 1
-  for (int r = 0; r < nrows; r++) {
+  for (int r = 0; r < (noz ? 0 : nrows); r++) {
     if constexpr (ZSL) {
       const long c = crow0 + sy * ((r < nrows_l) ? r : nrows_l - 1);
       const unsigned off = pin_v((unsigned)c * 8u);
@@ -213,8 +225,8 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   for (int v = 0; v < NV; v++) pf[v] = 0.0;
 
 #pragma unroll 1
-  for (int k = k0 - 1; k < k1; k++) {
-    const bool prime = (k == k0 - 1);
+  for (int k = noz ? k0 : k0 - 1; k < k1; k++) {
+    const bool prime = !noz && (k == k0 - 1);
     // carried from row to row inside this plane (y sweep frame): flux through the upper y face of the
     // previous row, y slope of the row being processed
     double Fy[NV], ysn[NV];
@@ -228,8 +240,9 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       const unsigned off_r = (unsigned)c * 8u, offb_r = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
       // the row visited after this one (next row of the plane, or the first row of the next plane)
       const long cn = (r + 1 < nrows) ? crow0 + sy * ((r + 1 < nrows_l) ? r + 1 : nrows_l - 1) + sz * (k - (k0 - 1))
-                                      : crow0 + sz * (k + 1 - (k0 - 1));
+                                      : (noz ? c : crow0 + sz * (k + 1 - (k0 - 1)));   // (2-D: no next plane)
       const unsigned offn_r = (unsigned)cn * 8u, offnb_r = (unsigned)cn;
+      const unsigned doff_n = offn_r - off_r, doffb_n = offnb_r - offb_r;
       double q0[NV], dU[NV];
       if (PF && !prime) {
 #pragma unroll
@@ -266,26 +279,23 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
         // left PtoU(p_new)[ERG] - PtoU(P)[ERG] of every domain cell (0 elsewhere)
         dU[uERG] += ldu(reinterpret_cast<const char *>(a.dE), pin_v(off_r));
       }
-      double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;
 
-#if PION_ROWS2_UNROLL_T
-      // the four tasks of a row (x face, lower y face of the first row, upper y face, upper z face) as four
-      // straight-line copies of the task body -- the flux body inlined in each -- instead of one body in a
-      // uniform loop: the task number is a compile-time constant of each copy, so the sweep-frame permutation,
-      // the edge-state arrays and what happens to the flux need no selects and no copies at a loop join
-      // (The two y tasks share ONE copy, run as a loop of one or two passes: the lower face of a row group and
-      // the upper face of the group below it are the same interface, solved by two wavefronts -- from one copy of
-      // the code both get the same bits in the fast build too, whose FMA contraction may differ between copies.)
-      auto task = [&](auto tc, const int t_run) __attribute__((always_inline)) {
+      // One task of a row: t = 0 the x face (c | c+1), t = 2 a y face, t = 3 the upper z face (c | c+sz).  The y task
+      // has two modes: the upper face of the row (c | c+sy) and -- `lower`, first row of a group only -- its lower
+      // face (c-sy | c), whose flux later rows get carried in registers.  Both modes run through ONE copy of the
+      // code: the lower face of a group and the upper face of the group below are the same interface, solved by two
+      // wavefronts, and from one copy both get the same bits in the fast build too (FMA contraction may differ from
+      // copy to copy).
+      // PION_ROWS2_COPIES: the task is a compile-time constant of each of three call sites (x, y, z), so the flux body
+      // is inlined three times and the sweep-frame permutation, the edge-state arrays and what happens to the flux
+      // need no selects and no copies at a loop join (first-order instance -6 %, second-order -1 %).
+      // (read-only scalars are captured by value, the per-task temporaries live inside: a `cond ? a : b` on two
+      // by-reference captures becomes a select of their addresses, which pins both to scratch memory)
+      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
         constexpr int TC = decltype(tc)::value;
-        const int t = (TC == 12) ? t_run : TC;
-        if (TC == 12) __builtin_assume(t == 1 || t == 2);
-#else
-#pragma unroll 1
-      for (int t = prime ? 3 : 0; t < 4; t++) {
-        if (t == 1 && r > 0) continue;  // lower y face: flux carried from the previous row
-#endif
+        const int t = (TC < 0) ? t_run : TC;
         double eL[NV], eR[NV], f[NV], pstar[NV];
+        double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;   // B_n / psi of the lower and the upper neighbour cell
         long cl, st;
         int ax;
         unsigned hfl = 0, hfr = 0;   // HLLD -> HLL switch flags of the two cells of the interface
@@ -344,96 +354,79 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             }
           }
         }
-        else if (t == 1) {
-          // first row of the group: lower y face (c-sy | c); slopes of rows j-1 and j
-          const unsigned off = pin_v(off_r), offb = pin_v(offb_r);   // (pin_v: offsets as this block sees them)
-          ax = 1;
-          st = sy;
-          cl = c - sy;
-          if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            if (PF) hfl = pfh;
-            else {
-              hfl = ldub(Ht - sy, offb);
-              hfr = ldub(Ht, offb);
-            }
-          }
-          double qm1[NV], yq0[NV];
-          if (PF) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) qm1[v] = pf[v];
-          }
-          else load_rot2<NV, MHD>(St, ncb, 1, -syb, off, qm1);
-          to_sweep<NV, MHD>(1, q0, yq0);
-          if (oa2) {
-            double qm2[NV], qp1[NV], sm1[NV];
-            load_rot2<NV, MHD>(St, ncb, 1, -2 * syb, off, qm2);
-            load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
-            hslope3<NV>(qm2, qm1, yq0, dx, thr, sm1);
-            hslope3<NV>(qm1, yq0, qp1, dx, thr, ysn);   // this row's slope, used again by the upper face
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-              eL[v] = qm1[v] + sm1[v] * 0.5;
-              eR[v] = yq0[v] - ysn[v] * 0.5;
-            }
-          }
-          else {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-              eL[v] = qm1[v];
-              eR[v] = yq0[v];
-            }
-          }
-        }
         else if (t == 2) {
-          // upper y face (c | c+sy): this row's slope is ysn (from the lower face or the previous row),
-          // the next row's slope is new and replaces it
+          // A y face between cell A (below) and cell B (above): upper mode A = this row, B = row j+1; lower mode
+          // A = row j-1, B = this row.  F is the one of the two that has to be fetched, C the row above B.
           const unsigned off = pin_v(off_r), offb = pin_v(offb_r);   // (pin_v: offsets as this block sees them)
           ax = 1;
           st = sy;
-          cl = c;
+          cl = lower ? c - sy : c;
+          const long shc = lower ? -sy : 0, shb = lower ? -syb : 0;   // shift of cell A from the lane's cell (uniform)
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
             if (PF) hfl = pfh;
             else {
-              hfl = ldub(Ht, offb);
-              hfr = ldub(Ht + sy, offb);
+              hfl = ldub(Ht + shc, offb);
+              hfr = ldub(Ht + shc + sy, offb);
             }
           }
-          double yq0[NV], qp1[NV];
+          double own[NV], F[NV], A[NV], B[NV];
           if (PF) {
 #pragma unroll
-            for (int v = 0; v < NV; v++) qp1[v] = pf[v];
+            for (int v = 0; v < NV; v++) F[v] = pf[v];
             bnm = pfb;
             sim = pfs;
           }
           else {
-            load_rot2<NV, MHD>(St, ncb, 1, syb, off, qp1);
+            load_rot2<NV, MHD>(St, ncb, 1, lower ? -syb : syb, off, F);
             if constexpr (MHD) {
-              bnm = ldu(St + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
-              if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - syb, off);
+              if (!lower) {
+                bnm = ldu(St + (long)rotvar<MHD>(1, qBN) * ncb - syb, off);
+                if constexpr (EQ == EQGLM) sim = ldu(St + (long)qSI * ncb - syb, off);
+              }
             }
           }
-          to_sweep<NV, MHD>(1, q0, yq0);
-          if (oa2) {
-            double qp2[NV], sp[NV];
-            load_rot2<NV, MHD>(St, ncb, 1, 2 * syb, off, qp2);
-            hslope3<NV>(yq0, qp1, qp2, dx, thr, sp);
+          to_sweep<NV, MHD>(1, q0, own);
+          if (lower) {
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-              eL[v] = yq0[v] + ysn[v] * 0.5;
-              eR[v] = qp1[v] - sp[v] * 0.5;
-              ysn[v] = sp[v];
+              A[v] = F[v];
+              B[v] = own[v];
             }
           }
           else {
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-              eL[v] = yq0[v];
-              eR[v] = qp1[v];
+              A[v] = own[v];
+              B[v] = F[v];
+            }
+          }
+          if (oa2) {
+            double C[NV], sB[NV];
+            load_rot2<NV, MHD>(St, ncb, 1, shb + 2 * syb, off, C);
+            if (lower) {
+              // the slope of row j-1 (an upper face finds its row's slope carried in ysn)
+              double M[NV];
+              load_rot2<NV, MHD>(St, ncb, 1, -2 * syb, off, M);
+              hslope3<NV>(M, A, B, dx, thr, ysn);
+            }
+            hslope3<NV>(A, B, C, dx, thr, sB);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = A[v] + ysn[v] * 0.5;
+              eR[v] = B[v] - sB[v] * 0.5;
+              ysn[v] = sB[v];   // the slope of B: of this row (lower mode), of the next row (upper mode)
+            }
+          }
+          else {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+              eL[v] = A[v];
+              eR[v] = B[v];
             }
           }
           if constexpr (MHD) {
-            bnp = qp1[qBN];
-            if constexpr (EQ == EQGLM) sip = qp1[qSI];
+            bnp = F[qBN];
+            if constexpr (EQ == EQGLM) sip = F[qSI];
           }
         }
         else {
@@ -513,7 +506,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           long psh, bsh = 0;   // byte shift of the row to load; of the lower neighbour's B_n / psi
           long hs1, hs2;       // the two switch flags
           bool wb = true, nextcell = false;
-          if (t == 3) {
+          if (t == 3 || (noz && t == 2 && !lower)) {
             // next: the x task of the next row; in the priming plane, where every row runs the z task
             // only, the z task of the next row (after its last row: the x task of the first row of the
             // next plane)
@@ -534,27 +527,30 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             }
           }
           else if (t == 0 && r == 0) {
+            // next: the lower y face of the group's first row
             pax = 1;
             psh = -syb;
             wb = false;
             hs1 = -sy;
             hs2 = 0;
           }
-          else if (t == 0 || t == 1) {
+          else if (t == 0 || lower) {
+            // next: the upper y face of this row
             pax = 1;
             psh = syb;
             bsh = -syb;
             hs1 = 0;
             hs2 = sy;
           }
-          else {   // t == 2: the z task of this row
+          else {   // an upper y face: next is the z task of this row
             pax = 2;
             psh = szb;
             bsh = -szb;
             hs1 = 0;
             hs2 = sz;
           }
-          const unsigned off = pin_v(nextcell ? offn_r : off_r), offb = pin_v(nextcell ? offnb_r : offb_r);
+          // (as arithmetic: a select between two captured values becomes a select of their addresses -> scratch)
+          const unsigned off = pin_v(off_r + (nextcell ? doff_n : 0u)), offb = pin_v(offb_r + (nextcell ? doffb_n : 0u));
           load_rot2<NV, MHD>(Sp, ncb, pax, psh, off, pf);
           if constexpr (MHD) {
             if (wb) {
@@ -572,18 +568,16 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           for (int v = 0; v < NV; v++) Fm[v] = lane_prev(f[v]);
           apply_axis<EQ, NV>(dU, q0, bnm, sim, bnp, sip, Fm, f, dt, dx);
         }
-        else if (t == 1) {
-#pragma unroll
-          for (int v = 0; v < NV; v++) Fy[v] = f[v];
-        }
         else if (t == 2) {
-          double d[NV], yq0[NV];
-          to_sweep<NV, MHD>(1, q0, yq0);
-          to_sweep<NV, MHD>(1, dU, d);
-          apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
-          from_sweep<NV, MHD>(1, d, dU);
+          if (!lower) {
+            double d[NV], yq0[NV];
+            to_sweep<NV, MHD>(1, q0, yq0);
+            to_sweep<NV, MHD>(1, dU, d);
+            apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
+            from_sweep<NV, MHD>(1, d, dU);
+          }
 #pragma unroll
-          for (int v = 0; v < NV; v++) Fy[v] = f[v];  // lower-face flux of the next row
+          for (int v = 0; v < NV; v++) Fy[v] = f[v];  // lower-face flux of this row (lower mode) / of the next row
         }
         else {
           if (!prime) {
@@ -598,16 +592,20 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
 #pragma unroll
           for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = f[v];
         }
-#if PION_ROWS2_UNROLL_T
       };
+#if PION_ROWS2_COPIES
       if (!prime) {
-        task(std::integral_constant<int, 0>{}, 0);
-        // lower y face only for the first row of the group (else: the flux carried from the previous row)
+        task(std::integral_constant<int, 0>{}, 0, false);
+        // the y task: for the first row of the group its lower face first
 #pragma unroll 1
-        for (int ty = (r == 0) ? 1 : 2; ty < 3; ty++) task(std::integral_constant<int, 12>{}, ty);
+        for (int m = (r == 0) ? 1 : 0; m >= 0; m--) task(std::integral_constant<int, 2>{}, 2, m != 0);
       }
-      task(std::integral_constant<int, 3>{}, 3);
+      if (!noz) task(std::integral_constant<int, 3>{}, 3, false);
 #else
+#pragma unroll 1
+      for (int t = prime ? 3 : 0; t < 4; t++) {
+        if ((t == 1 && r > 0) || (t == 3 && noz)) continue;
+        task(std::integral_constant<int, -1>{}, (t == 1) ? 2 : t, t == 1);
       }
 #endif
 
@@ -700,14 +698,15 @@ static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
   constexpr int NV = Eqn<EQ, NTR>::NV;
   constexpr int NZ = ZSL ? 2 * NV : NV;
   StageArgs a = a0;
-  const int rmax = rows2_rmax<NV, ZSL>();
+  const bool noz = (a.g.ndim == 2);
+  const int rmax = noz ? 64 : rows2_rmax<NV, ZSL>();   // (2-D: nothing is carried in LDS)
   if (a.rows > rmax) a.rows = rmax;
   if (a.rows < 1) a.rows = 1;
   const int R = a.rows;
-  const int nzc = (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
+  const int nzc = ((a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk) + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
   const long ntiles = (long)rows_tiling(a).per_chunk * nzc;
   const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
-  const size_t shmem = sizeof(double) * 4 * R * NZ * 64;
+  const size_t shmem = noz ? 0 : sizeof(double) * 4 * R * NZ * 64;
   // compile-time spatial order and "no H-correction / microphysics" for the production instances
   // (MHD HLLD, Euler Roe-CV, Euler FVS), run-time for the others
   constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)

@@ -110,3 +110,43 @@ def test_rows_per_wavefront_do_not_change_the_result(case, strict, monkeypatch):
     for rows in ("1", "3"):
         assert out[rows][1] == out[None][1]
         assert np.array_equal(out[rows][0], out[None][0]), rows
+
+
+# ---- 2-D Cartesian grids run the same kernel without its z part (rows marched along y) -----------
+GRIDS_2D = [[130, 37], [70, 19], [24, 64]]
+
+
+@pytest.mark.parametrize("ng", GRIDS_2D, ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("case", CASES)
+def test_2d_rows_kernel_strict_bitexact_vs_oracle(case, ng):
+    cfg, P = _case(case, ng, 1)
+    run_pair(cfg, P, 3)
+
+
+@pytest.mark.parametrize("ng", GRIDS_2D[:2], ids=lambda g: "x".join(map(str, g)))
+@pytest.mark.parametrize("case", CASES)
+def test_2d_rows_kernel_fast_vs_oracle(case, ng):
+    cfg, P = _case(case, ng, 0)
+    run_pair(cfg, P, 3, strict=False, tol=3e-11)
+
+
+@pytest.mark.parametrize("case", ["glm_hlld", "hd_roe"])
+@pytest.mark.parametrize("rows", ["1", "3", "20"])
+def test_2d_rows_per_wavefront_and_cell_kernel_agree(case, rows, monkeypatch):
+    """rows per wavefront (PION_ROWS) only move work between wavefronts; PION_ROWS_2D=0 is the cell-per-thread
+    kernel: the strict build gives the same bits every way, first-order-in-space grids (OA1) included"""
+    out = []
+    for env in ({}, {"PION_ROWS": rows}, {"PION_ROWS_2D": "0"}):
+        for k in ("PION_ROWS", "PION_ROWS_2D"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg, P = _case(case, [70, 41], 1)
+        with _gpu(cfg) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            sc.time_int(3)
+            out.append((g.download(0), sc.simtime))
+    for A, t in out[1:]:
+        assert t == out[0][1]
+        assert np.array_equal(A, out[0][0])

@@ -63,6 +63,39 @@ def test_gpu_strict_reproduces_reference_shock_tube(gold, name):
         assert np.array_equal(A, gold[name + "_P"]), name
 
 
+# Gate of the fast build per case: the SURVEY 8(d) 1e-10 x refvec, except where the REFERENCE ALGORITHM itself is
+# that ill-conditioned: Ryu & Jones 4a (a switch-on fast shock: B_y = 0 exactly on one side, B_z = 0 on both)
+# answers a 1-ulp change of its INPUT with 7e-10 (L1) / 2e-9 (L2) / 2e-8 (max) x refvec in the end state --
+# test_reference_amplifies_one_ulp_in_rj4a below measures that on the oracle -- so no build-independent answer
+# exists below that level and the gate there is 25 x the measured sensitivity.
+FAST_GATE = {"rj4a": 5e-8}
+
+
+def _one_ulp_sensitivity(name):
+    from cpu_backends import CpuSim
+    cfg, P, tf = gc.shock_tube_case(name)
+    outs = []
+    for pert in (0, 1):
+        Q = P.copy()
+        if pert:
+            Q = np.nextafter(Q, np.inf)
+            Q[P == 0] = 0.0
+        with CpuSim(cfg, "orc") as o:
+            gc.end_run(o, cfg, Q, tf, 100000)
+            outs.append(o.download(0))
+    return gc.diff_norms(cfg, outs[0], outs[1])
+
+
+def test_reference_amplifies_one_ulp_in_rj4a():
+    """conditioning of the shipped problems under the reference's own arithmetic (the oracle is bit-identical to
+    it on these runs): one ulp on the initial state moves RJ 4a's end state by > 1e-10 x refvec, and a
+    well-conditioned neighbour (RJ 4b) by < 1e-12"""
+    l1, l2, mx = _one_ulp_sensitivity("rj4a")
+    assert l2.max() > 1e-10 and l2.max() < 2e-9 * 5
+    l1, l2, mx = _one_ulp_sensitivity("rj4b")
+    assert l2.max() < 1e-12
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", gc.SHOCK_TUBES)
 def test_gpu_fast_build_shock_tube_norms(gold, name):
@@ -75,4 +108,5 @@ def test_gpu_fast_build_shock_tube_norms(gold, name):
     assert n == int(gold[name + "_n"]), (n, int(gold[name + "_n"]))
     assert abs(t - float(gold[name + "_t"])) <= 1e-12 * abs(t)
     l1, l2, mx = gc.diff_norms(cfg, A, gold[name + "_P"])
-    assert l1.max() <= 1e-10 and l2.max() <= 1e-10, (name, l1, l2, mx)
+    gate = FAST_GATE.get(name, 1e-10)
+    assert l1.max() <= gate and l2.max() <= gate, (name, l1, l2, mx)
