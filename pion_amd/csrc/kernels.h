@@ -38,7 +38,27 @@ struct CoolDev {
   double MinT_allowed, MaxT_allowed;
 };
 
-#define PION_MAX_ZCHUNKS 47
+// Uneven plane chunks of a strip of np planes: chunk number cz covers [*k0, *k1) (relative to the strip); returns the
+// number of chunks.  A rule instead of a table in the kernel arguments: indexing an argument array with a run-time
+// index makes the compiler copy the whole argument struct to scratch memory (measured: the stage kernel 2x slower).
+__host__ __device__ inline int zchunk_bounds(const int np, const int cmax, const int cz, int *k0, int *k1)
+{
+  int n = 0, pos = 0;
+  *k0 = *k1 = np;
+  while (pos < np) {
+    const int rem = np - pos;
+    int c = (rem > 2 * cmax) ? cmax : ((rem / 2 > 4) ? rem / 2 : 4);
+    if (c > cmax) c = cmax;
+    if (c > rem || rem - c < 3) c = rem;
+    if (n == cz) {
+      *k0 = pos;
+      *k1 = pos + c;
+    }
+    pos += c;
+    n++;
+  }
+  return n;
+}
 struct StageArgs {
   GridDesc g;
   const double *S;    // stencil state ("Ph")      [nvar][ncell]
@@ -60,10 +80,10 @@ struct StageArgs {
   int zslope_lds;     // k_stage_rows2: carry the z slope in LDS (else rebuild it from plane k-1)
   double *dE;         // k_stage_rows2: cooling source PtoU(p_new)[ERG]-PtoU(P)[ERG] per cell from k_cooling_dE (or null)
   int zchunk;         // planes per wavefront in the marching kernels
-  // k_stage_rows2, first strip [kz0,kz1): nzb > 0 = uneven chunks, chunk i covers planes kz0 + zb[i] .. kz0 + zb[i+1]
-  // (long chunks first, short ones last: the launch's last wavefronts are short, so its tail is)
-  int nzb;
-  short zb[PION_MAX_ZCHUNKS + 1];
+  // k_stage_rows2, first strip [kz0,kz1): nzb > 0 = uneven chunks (zchunk_bounds below: chunks of `zcmax` planes,
+  // then halving down to 4 -- long chunks first, short ones last: the launch's last wavefronts are short, so its
+  // tail is), nzb of them
+  int nzb, zcmax;
   int rows;           // y-rows per wavefront in k_stage_rows2
   int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows2; k_stage: whole grid)
   int kz2, kz3;       // and a second strip [kz2,kz3) (empty when kz3 <= kz2): the two z-boundary strips

@@ -1406,19 +1406,10 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   // about a third of a plane visit (its z task only).  512 planes: 14 x 32, 32, 16, 8, 4, 4; a 64-plane slab:
   // 32, 16, 8, 4, 4 (equal chunks: 3.25 ms/step for 512 x 512 x 64, 88 % of the per-cell rate of 512^3).
   a.nzb = 0;
+  a.zcmax = (h->zchunk > 0) ? h->zchunk : 32;
   if (a.use_march != 0 && h->uneven_chunks && kz1 - kz0 >= 16) {
-    const int np = kz1 - kz0, cmax = (h->zchunk > 0) ? h->zchunk : 32;
-    int n = 0, pos = 0;
-    a.zb[0] = 0;
-    while (pos < np && n < PION_MAX_ZCHUNKS) {
-      const int rem = np - pos;
-      int c = (rem > 2 * cmax) ? cmax : ((rem / 2 > 4) ? rem / 2 : 4);
-      if (c > cmax) c = cmax;
-      if (c > rem || rem - c < 3) c = rem;
-      pos += c;
-      a.zb[++n] = (short)pos;
-    }
-    if (pos == np) a.nzb = n;
+    int k0, k1;
+    a.nzb = zchunk_bounds(kz1 - kz0, a.zcmax, 0, &k0, &k1);
   }
   if (cfg.cooling != 0 && a.use_march != 0) {
     // calc_noRT_microphysics_dU as its own launch (thread per cell, full occupancy): dE per cell

@@ -122,12 +122,17 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   const int nyg = tl.nyg;
   const int nzc1 = (a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk;
   const int nzc = nzc1 + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;   // chunks of both strips
-  const long ntiles = (long)tl.per_chunk * nzc;
   // the wavefront number is uniform: say so, and the tile / row / plane loops run on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long tile = xcd_tile(blockIdx.x, (ntiles + 3) / 4) * 4 + wave;
-  if (tile >= ntiles) return;  // whole wavefront leaves together (no block-level barrier is used)
-  const int cz = (int)(tile / tl.per_chunk), tt = (int)(tile % tl.per_chunk);
+  // Workgroup -> (x-y tile group, plane chunk).  Workgroups go to the XCDs round robin (blockIdx % 8): each XCD
+  // takes an eighth of the x-y tiles -- y-adjacent row groups, whose halo rows are each other's own rows, share its
+  // L2 -- through ALL plane chunks, in chunk order: with uneven chunks (long first) every XCD ends on the short ones.
+  // (Chunk-major over the whole grid would hand the long chunks to some XCDs and the short ones to others.)
+  const int nb4 = (tl.per_chunk + 3) / 4, nb8 = (nb4 + 7) / 8;   // workgroups per chunk; per chunk and XCD
+  const int lb = (int)(blockIdx.x >> 3);
+  const int cz = lb / nb8, bq = (int)(blockIdx.x & 7) * nb8 + lb % nb8;
+  const int tt = bq * 4 + wave;
+  if (cz >= nzc || bq >= nb4 || tt >= tl.per_chunk) return;  // whole wavefront leaves together (no block-level barrier is used)
   const int lane = threadIdx.x & 63;
   int ix, jg, jg_first;   // jg: this LANE's row group; jg_first: the wavefront's first (uniform)
   bool writer;
@@ -160,8 +165,9 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   const int nrows_l = (j0 + R <= a.g.ng[1]) ? R : a.g.ng[1] - j0;
   int k0, k1;
   if (a.nzb > 0 && cz < nzc1) {
-    k0 = a.kz0 + a.zb[cz];
-    k1 = a.kz0 + a.zb[cz + 1];
+    zchunk_bounds(a.kz1 - a.kz0, a.zcmax, cz, &k0, &k1);   // (scalar unit: cz is uniform)
+    k0 += a.kz0;
+    k1 += a.kz0;
   }
   else {
     k0 = (cz < nzc1) ? a.kz0 + cz * a.zchunk : a.kz2 + (cz - nzc1) * a.zchunk;
@@ -704,8 +710,8 @@ static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
   if (a.rows < 1) a.rows = 1;
   const int R = a.rows;
   const int nzc = ((a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk) + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
-  const long ntiles = (long)rows_tiling(a).per_chunk * nzc;
-  const long nblocks = (((ntiles + 3) / 4 + 7) / 8) * 8;
+  const int nb4 = (rows_tiling(a).per_chunk + 3) / 4, nb8 = (nb4 + 7) / 8;
+  const long nblocks = 8L * nb8 * nzc;   // (see the kernel: an eighth of the x-y tiles per XCD, through all chunks)
   const size_t shmem = noz ? 0 : sizeof(double) * 4 * R * NZ * 64;
   // compile-time spatial order and "no H-correction / microphysics" for the production instances
   // (MHD HLLD, Euler Roe-CV, Euler FVS), run-time for the others

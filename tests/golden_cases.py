@@ -348,7 +348,7 @@ COOL_DTS = [1.0e3, 1.0e9, 3.0e10, 1.0e12]   # seconds: Euler shortcut ... many c
 
 
 STEP_CASES_C = ["cool_fvs_3d", "cool_roe_3d"]        # steps_c.npz: whole steps with the reference's mp_only_cooling
-END_CASES_C = ["cool3d_n20"]                         # endstate_c.npz
+END_CASES_C = ["cool3d_n20", "mhd_ideal_generic_64x96"]   # endstate_c.npz
 
 
 def step_case_c(name, strict_fp=1):
@@ -363,6 +363,13 @@ def end_case_c(name, strict_fp=1):
     if name == "cool3d_n20":
         cfg, P = problems.cooling_blast3d(20, strict_fp=strict_fp)
         return cfg, P, 1.0e30, 60
+    if name == "mhd_ideal_generic_64x96":
+        # ideal MHD + HLLD (the solver of BASELINE config 3 / the nvar-8 row of the headline) on a blast WITHOUT the
+        # degeneracies of the shipped symmetric one (B_z != 0, a velocity field of definite divergence:
+        # problems.mhd_blast_generic; the reference is continuous there, tests/test_reference_conditioning.py), 220
+        # steps: the long-run cell-wise gate of the fast ideal-MHD path
+        cfg, P = problems.mhd_blast_generic([64, 96], abi.EQMHD, abi.FLUX_RS_HLLD, strict_fp=strict_fp)
+        return cfg, P, 1.0e30, 220
     raise KeyError(name)
 
 

@@ -65,7 +65,9 @@ FAST_TOL = {
     "mhd_bw2d_64x96": (1e-10, 1e-10),
     # the symmetric blast in ideal MHD is a discontinuity of the reference algorithm itself (1 ulp in ->
     # 2e-4 out after two steps, tests/test_reference_conditioning.py): no build-independent end state exists
-    # cell by cell; the conserved totals do not care which branch a degenerate interface took
+    # cell by cell; the conserved totals do not care which branch a degenerate interface took.  (The cell-wise
+    # long-run gate of the fast ideal-MHD path is the well-conditioned blast mhd_ideal_generic_64x96, 220 steps
+    # against the reference's end state: tests/test_cooling_reference.py, END_CASES_C.)
     "mhd_ideal_bw2d_64x96": (None, 1e-10),
     "bw3d_nr032": (1e-10, 1e-10),
 }
