@@ -1406,7 +1406,21 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   // about a third of a plane visit (its z task only).  512 planes: 14 x 32, 32, 16, 8, 4, 4; a 64-plane slab:
   // 32, 16, 8, 4, 4 (equal chunks: 3.25 ms/step for 512 x 512 x 64, 88 % of the per-cell rate of 512^3).
   a.nzb = 0;
-  a.zcmax = (h->zchunk > 0) ? h->zchunk : 32;
+  a.zcmax = 32;
+  if (h->zchunk > 0) a.zcmax = h->zchunk;
+  else if (a.use_march != 0) {
+    // longest chunk: at least ~4 wavefronts per slot over the launch (Euler instances run three workgroups per CU,
+    // the MHD ones two), between 8 and 32 planes (256^3 Euler: 11 planes; even chunks of the model 3.05 ms/step,
+    // uneven ones from 32 down 3.28)
+    int rows = a.rows < 1 ? 1 : a.rows;
+    const int nyg = (h->g.ng[1] + rows - 1) / rows;
+    const int ntx_full = h->g.ng[0] / 62, rem = h->g.ng[0] - ntx_full * 62;
+    const int spw = (rem > 0) ? 64 / (rem + 2) : 0;
+    const long per_chunk = (long)ntx_full * nyg + ((rem > 0) ? (nyg + spw - 1) / spw : 0);
+    const long slots = ((cfg.eqntype == PION_EQEUL) ? 12L : 8L) * (h->ncu > 0 ? h->ncu : 256);
+    long c = (long)(kz1 - kz0) * per_chunk / (4 * slots);
+    a.zcmax = (int)(c < 8 ? 8 : (c > 32 ? 32 : c));
+  }
   if (a.use_march != 0 && h->uneven_chunks && kz1 - kz0 >= 16) {
     int k0, k1;
     a.nzb = zchunk_bounds(kz1 - kz0, a.zcmax, 0, &k0, &k1);

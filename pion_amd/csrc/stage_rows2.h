@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
   // per task and have no registers left for them)
   double pf[NV], pfb = 0.0, pfs = 0.0;
   unsigned pfh = 0;
+  bool pf_valid = false;   // a request has been made (false for the first task a wavefront runs)
 #pragma unroll
   for (int v = 0; v < NV; v++) pf[v] = 0.0;
 
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       const unsigned offn_r = (unsigned)cn * 8u, offnb_r = (unsigned)cn;
       const unsigned doff_n = offn_r - off_r, doffb_n = offnb_r - offb_r;
       double q0[NV], dU[NV];
-      if (PF && !prime) {
+      if (PF && pf_valid && !prime) {
 #pragma unroll
         for (int v = 0; v < NV; v++) q0[v] = pf[v];   // requested before the previous row's last solve
       }
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           st = 1;
           cl = c;
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            if (PF) hfl = pfh;   // (both flags, packed)
+            if (PF && pf_valid) hfl = pfh;   // (both flags, packed)
             else {
               hfl = ldub(Ht, offb);
               hfr = ldub(Ht + 1, offb);
@@ -369,14 +370,14 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           cl = lower ? c - sy : c;
           const long shc = lower ? -sy : 0, shb = lower ? -syb : 0;   // shift of cell A from the lane's cell (uniform)
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            if (PF) hfl = pfh;
+            if (PF && pf_valid) hfl = pfh;
             else {
               hfl = ldub(Ht + shc, offb);
               hfr = ldub(Ht + shc + sy, offb);
             }
           }
           double own[NV], F[NV], A[NV], B[NV];
-          if (PF) {
+          if (PF && pf_valid) {
 #pragma unroll
             for (int v = 0; v < NV; v++) F[v] = pf[v];
             bnm = pfb;
@@ -442,14 +443,14 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           st = sz;
           cl = c;
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) {
-            if (PF && !(prime && r == 0)) hfl = pfh;
+            if (PF && pf_valid) hfl = pfh;
             else {
               hfl = ldub(Ht, offb);
               hfr = ldub(Ht + sz, offb);
             }
           }
           double zq0[NV], qp1[NV];
-          if (PF && !(prime && r == 0)) {
+          if (PF && pf_valid) {
 #pragma unroll
             for (int v = 0; v < NV; v++) qp1[v] = pf[v];
             bnm = pfb;
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             }
           }
           if constexpr (MHD && SOLVER == FLUX_RS_HLLD) pfh = ldub(Hp + hs1, offb) | ldub(Hp + hs2, offb);
+          pf_valid = true;
         }
         FX::intercell_flux(eL, eR, f, pstar, fc, hc_eta, use_hll, err);
 

@@ -96,8 +96,11 @@ def test_gpu_fast_build_end_state_norms(gold, name):
             n, t, int(gold[name + "_n"]), float(gold[name + "_t"])))
 
 
-# ---- config 5 (Wind3D + cooling) at low resolution: no reference fixture can exist (the cooling tables need GSL,
-# "parity unpinned"), so the yardstick is the oracle run on the same inputs -----------------------
+# ---- config 5 (Wind3D + cooling) at low resolution.  The cooling physics is pinned to the reference's own
+# mp_only_cooling (tests/test_cooling_reference.py: tables, Edot, TimeUpdateMP, timescales, whole steps and a 60-step
+# run of the same equations / solver / microphysics without the wind source).  What the reference objects cannot run
+# here is the stellar-wind SOURCE (grid/stellar_wind_BC.cpp needs GSL): the wind-cell states are "parity unpinned",
+# and for the full configuration the yardstick is the oracle run on the same inputs -------------------------------
 def _wind_setup():
     from pion_amd import cooling, problems
     cfg, P, (idx, st), dtl = problems.wind3d(32, strict_fp=1)
@@ -127,7 +130,7 @@ def _wind_run(sim, cfg, P, setup, dtl, nsteps):
 def test_gpu_wind3d_32_sixty_steps_vs_oracle(strict):
     """Wind3D single level 32^3 (Euler + tracer, FVS, cooling 8 with the cooling-time limit, stellar-wind cells,
     reflecting / one-way boundaries), 60 steps: strict build = oracle bit for bit (every dt, the end state);
-    fast build: L1 / L2 <= 1e-10 x refvec.  PARITY UNPINNED against the reference (oracle only)."""
+    fast build: L1 / L2 <= 1e-10 x refvec.  The wind-cell states are PARITY UNPINNED against the reference."""
     from cpu_backends import CpuSim
     from pion_amd import lib
     cfg, P, setup, dtl = _wind_setup()
