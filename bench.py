@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.
 
 def kernel_source_hash():
     """hash of the CODE of pion_amd/csrc (// comments and blank lines dropped, so that a comment edit does not
-    invalidate the committed PMC measurements; the same function as profiles/tools/summarize_r02.py)"""
+    invalidate the committed PMC measurements; the same function as profiles/tools/summarize_r03.py)"""
     import hashlib
     import re
     h = hashlib.sha256()
@@ -510,14 +510,14 @@ def main():
         achieved = alg_bytes / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
         # Bytes per stage launch that left L2, from the PMC passes of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read correction calibrated on 8 B/lane accesses):
-        # profiles/r02_pmc_traffic.json, written by profiles/tools/summarize_r02.py.  Counters cannot be read
+        # profiles/r03_pmc_traffic.json, written by profiles/tools/summarize_r03.py.  Counters cannot be read
         # from inside this process, so the committed measurement is quoted -- only for the workload it was
         # taken on (512^3, GLM, fast mode, 1 GPU) and only while the kernel sources still hash to what it was
         # taken on; otherwise null.
         traffic = None
         valu = None
         pdir = os.path.join(ROOT, "profiles")
-        tfile, sfile = os.path.join(pdir, "r02_pmc_traffic.json"), os.path.join(pdir, "r02_pmc_sq_stage_kernel.json")
+        tfile, sfile = os.path.join(pdir, "r03_pmc_traffic.json"), os.path.join(pdir, "r03_pmc_sq.json")
         if (world == 1 and not loopback and n == 512 and not args.nz and eq == abi.EQGLM and not args.strict
                 and args.workload == "m1"):
             src = kernel_source_hash()
@@ -536,7 +536,7 @@ def main():
                     valu = {"valu_insts_per_launch": c["SQ_INSTS_VALU"],
                             "valu_active_frac_of_wave_cycles": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
                             "waitcnt_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
-                            "waves_per_simd": 2, "source": "profiles/r02_pmc_sq_stage_kernel.json"}
+                            "waves_per_simd": 2, "source": "profiles/r03_pmc_sq.json"}
                     # the roofline that actually binds: every wave-level VALU instruction of this fp64 kernel holds
                     # its SIMD's vector pipe for 4 cycles (16 fp64 lanes per clock per SIMD, 78.6 TFLOP/s spec);
                     # fraction of that issue capacity the launch used, at the nominal 2.4 GHz
@@ -558,7 +558,7 @@ def main():
                          "step_frac": value * 1e6 * 5 * nvar * 8 / (HBM_PEAK_GBS * 1e9 * world),
                          "step_frac_what": "SURVEY 8(d): whole-step rate x 5 nvar 8 B per cell-update / (peak x GPUs): "
                                            "prepass, boundary and reduction launches included",
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r02_pmc_traffic.json; null when the kernel sources have changed since)",
+                         "traffic": traffic, "traffic_unit": "bytes per launch that left L2 (PMC FETCH_SIZE + WRITE_SIZE, calibrated; profiles/r03_pmc_traffic.json; null when the kernel sources have changed since)",
                          "kernel": {"m1": "k_stage_rows2<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows2<MHD,0,HLLD>",
                                     "m2": "k_stage_rows2<EUL,0,Roe-CV>", "m3": "k_stage_rows2<EUL,1,FVS>",
                                     "dmr2d": "2-D stage kernel <EUL,0,Roe-CV>", "mhd2d": "2-D stage kernel <GLM,0,HLLD>"}[args.workload]

@@ -47,9 +47,10 @@ __host__ __device__ inline int zchunk_bounds(const int np, const int cmax, const
   *k0 = *k1 = np;
   while (pos < np) {
     const int rem = np - pos;
-    int c = (rem > 2 * cmax) ? cmax : ((rem / 2 > 4) ? rem / 2 : 4);
+    const int cmin = (np <= 128) ? 2 : 4;   // (a slab of a few dozen planes: its tail is a larger share of the launch)
+    int c = (rem > 2 * cmax) ? cmax : ((rem / 2 > cmin) ? rem / 2 : cmin);
     if (c > cmax) c = cmax;
-    if (c > rem || rem - c < 3) c = rem;
+    if (c > rem || rem - c < cmin) c = rem;
     if (n == cz) {
       *k0 = pos;
       *k1 = pos + c;

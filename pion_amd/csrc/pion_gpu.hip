@@ -1364,8 +1364,15 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
              && cfg.bc_type[1] == PION_BC_PERIODIC && h->g.ng[0] >= 2 * h->g.nbc[0]) ? 1 : 0;
   if (a.use_march != 0 && h->g.ndim == 2) {
     // 2-D: rows per wavefront marched along y (nothing in LDS): 2 + 1/R solves per cell against the number of
-    // wavefronts; 8 keeps >= 4 rounds of wavefronts on grids from 2048 x 512 up (PION_ROWS overrides)
-    a.rows = (h->rows > 0) ? h->rows : 8;
+    // wavefronts (measured, 4096 x 1260 Euler Roe-CV / 4096 x 6144 GLM-MHD HLLD, Mcell-updates/s: R = 4 7694 / 5940,
+    // 8 11360 / 7711, 16 12686 / 8034, 32 13076 / 7371; the cell-per-thread kernel 4680 / 2176); fewer rows on
+    // small grids so that every slot still gets a wavefront (PION_ROWS overrides)
+    int r2 = 16;
+    {
+      const long ntx = (h->g.ng[0] + 61) / 62;
+      while (r2 > 2 && ntx * ((h->g.ng[1] + r2 - 1) / r2) < 8L * (h->ncu > 0 ? h->ncu : 256)) r2 /= 2;
+    }
+    a.rows = (h->rows > 0) ? h->rows : r2;
     if (a.rows > 64) a.rows = 64;
   }
   else if (a.use_march != 0)

@@ -19,6 +19,23 @@ __global__ __launch_bounds__(256) void k_calib(const double *in, double *out, lo
   for (int v = 0; v < NWRITE; v++) out[v * n + i] = s + v;
 }
 
+// The stage kernel's x tiling on one variable plane: rows of NXA = 516 doubles (512 + 2 x 2 ghosts), one wavefront per
+// 62-cell tile reading 64 consecutive doubles from x0 = 62 * tile + 1 (so that wavefront reads start off the 128-byte
+// line grid and neighbouring tiles overlap by two cells), every row once.  Unique bytes touched = rows * 516 * 8:
+// what FETCH_SIZE x correction should give if the correction measured on aligned streams also holds for this pattern.
+__global__ __launch_bounds__(256) void k_calib_tiles(const double *in, double *out, long nrows)
+{
+  const int NXA = 516, NT = 9;   // 8 full tiles + the 16-cell remainder
+  const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long row = w / NT;
+  const int tile = (int)(w % NT), lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  int x = 62 * tile + 1 + lane;
+  if (x > NXA - 1) x = NXA - 1;
+  const double v = in[row * NXA + x];
+  if (lane == 0 && v == 12345.678) out[0] = v;   // (keeps the load; never true for the zero-filled input)
+}
+
 int main()
 {
   const long n = 1L << 27;  // 1 GiB per plane
@@ -31,6 +48,12 @@ int main()
   for (int rep = 0; rep < 3; rep++) {
     hipLaunchKernelGGL((k_calib<4, 1>), dim3(nb), dim3(256), 0, 0, in, out, n);  // 4 GiB read, 1 GiB written
     hipLaunchKernelGGL((k_calib<1, 2>), dim3(nb), dim3(256), 0, 0, in, out, n);  // 1 GiB read, 2 GiB written
+  }
+  {
+    const long nrows = (4L * n) / 516;   // the whole 4 GiB input as rows of 516 doubles
+    const unsigned nbt = (unsigned)((nrows * 9 + 3) / 4);
+    for (int rep = 0; rep < 3; rep++) hipLaunchKernelGGL(k_calib_tiles, dim3(nbt), dim3(256), 0, 0, in, out, nrows);
+    printf("k_calib_tiles reads %ld unique B (rows of 516 doubles, 62-cell tiles of 64 lanes)\n", nrows * 516 * 8);
   }
   (void)hipDeviceSynchronize();
   printf("calib done: k_calib<4,1> reads %ld B writes %ld B; k_calib<1,2> reads %ld B writes %ld B\n",
