@@ -99,7 +99,7 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #define PION_ROWS2_COPIES 1
 #endif
 #ifndef PION_ROWS2_U0
-#define PION_ROWS2_U0 1
+#define PION_ROWS2_U0 2
 #endif
 
 // workgroups per CU the register allocation aims at
@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       // ((U0 + dU_x) + dU_y) + dU_z instead of the reference's U0 + ((dU_x + dU_y) + dU_z) (same sum up to
       // rounding; the strict build keeps the reference's order).  At the end of the row, where the reference form
       // needs P0, a load would be waited for with nothing to overlap it.
+      // PION_ROWS2_U0 = 2: the loads go out in the x task, AFTER the loads the x task itself waits for (loads return
+      // in issue order), straight into dU's registers, and are converted in place after the x solve: a read of HBM
+      // that nothing waits for.
       const bool u0 = PLAIN && !same_pc && !prime && a.plain_cells;
+#if PION_ROWS2_U0 == 1
       if (u0) {
         const unsigned o = pin_v(off_r);
         const unsigned zu0 = opaque_zero();
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
         for (int v = 0; v < NV; v++) P0[v] = ldu_once(Pcb0 + v * ncb, o);
         E::PtoU(P0, dU, g);
       }
+#endif
 #else
       const bool u0 = false;
 #endif
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       // need no selects and no copies at a loop join (first-order instance -6 %, second-order -1 %).
       // (read-only scalars are captured by value, the per-task temporaries live inside: a `cond ? a : b` on two
       // by-reference captures becomes a select of their addresses, which pins both to scratch memory)
-      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
+      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz, u0](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
         constexpr int TC = decltype(tc)::value;
         const int t = (TC < 0) ? t_run : TC;
         double eL[NV], eR[NV], f[NV], pstar[NV];
@@ -327,6 +332,14 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
               qm[v] = ldu(St + v * ncb - 8, off);
               qp[v] = ldu(St + v * ncb + 8, off);
             }
+#if defined(PION_FAST_MATH) && PION_ROWS2_U0 == 2
+            if (u0) {
+              // the start-of-step state, into dU's registers (converted after the solve)
+              const char *const Pcb0 = reinterpret_cast<const char *>(a.Pc) + zt;
+#pragma unroll
+              for (int v = 0; v < NV; v++) dU[v] = ldu_once(Pcb0 + v * ncb, off);
+            }
+#endif
             hslope3<NV>(qm, q0, qp, dx, thr, sx);
 #pragma unroll
             for (int v = 0; v < NV; v++) {
@@ -574,6 +587,14 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           double Fm[NV];
 #pragma unroll
           for (int v = 0; v < NV; v++) Fm[v] = lane_prev(f[v]);
+#if defined(PION_FAST_MATH) && PION_ROWS2_U0 == 2
+          if (u0) {
+            double P0[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) P0[v] = dU[v];
+            E::PtoU(P0, dU, g);
+          }
+#endif
           apply_axis<EQ, NV>(dU, q0, bnm, sim, bnp, sip, Fm, f, dt, dx);
         }
         else if (t == 2) {
