@@ -146,6 +146,7 @@ struct CoolTestArgs {
   int stage_rows2_rows(int eq, int ntr, int zslope_lds, int want); \
   int launch_prepass(const PrepassArgs &a, hipStream_t s);         \
   int launch_dt(const DtArgs &a, hipStream_t s);                   \
+  int launch_dt_mp(const DtArgs &a, hipStream_t s);                \
   int launch_flux_test(const FluxTestArgs &a, hipStream_t s);      \
   int launch_cool_update(const CoolTestArgs &a, hipStream_t s);    \
   int launch_cool_edot(const CoolTestArgs &a, hipStream_t s);      \

@@ -1106,6 +1106,50 @@ __global__ __launch_bounds__(256) void k_dt(const DtArgs a)
   if (err) atomicOr(a.errword, err);
 }
 
+// The cooling time alone (calc_microphysics_dt -> get_mp_timescales_no_radiation, calc_timestep.cpp:405-507;
+// mp_only_cooling::timescales, mp_only_cooling.cpp:333-368), rate tables in LDS as in k_cooling_dE: a time scale is two
+// Edot evaluations = two bisections of eight dependent look-ups each, which through global memory cost the fused
+// reduction of the stage kernel a third of its run time (Wind3D 256^3, second-order instance: 1.58 ms with it, 1.03
+// without; this kernel: see DESIGN.md s4.1).  Min over cells with !isbd && isleaf into result[1].
+__global__ __launch_bounds__(256) void k_dt_mp(const DtArgs a)
+{
+  __shared__ double ctab[11 * PION_COOL_NT_MAX];
+  const int NT = a.cool.NT;
+  for (int i = threadIdx.x; i < NT; i += 256) ctab[i] = a.cool.T[i];
+  for (int i = threadIdx.x; i < 5 * NT; i += 256) {
+    ctab[NT + i] = a.cool.tab[i];
+    ctab[6 * NT + i] = a.cool.slope[i];
+  }
+  __syncthreads();
+  CoolDev cool = a.cool;
+  cool.T = ctab;
+  cool.tab = ctab + NT;
+  cool.slope = ctab + 6 * NT;
+  const long nc = a.g.ncell;
+  const long non = (long)a.g.ng[0] * a.g.ng[1] * a.g.ng[2];
+  double tmp = 1.0e99;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < non; k += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(k % a.g.ng[0]), iy = (int)((k / a.g.ng[0]) % a.g.ng[1]),
+              iz = (int)(k / ((long)a.g.ng[0] * a.g.ng[1]));
+    const long c = (long)(ix + a.g.nbc[0]) + a.g.sy * (iy + a.g.nbc[1]) + a.g.sz * (iz + a.g.nbc[2]);
+    const uint8_t fl = a.flags[c];
+    if (!(fl & 2) && (fl & 16)) {
+      const double t = Cooling::timescale(cool, a.Ph[0 * nc + c], a.Ph[1 * nc + c], a.gamma);
+      tmp = (t < tmp) ? t : tmp;
+    }
+  }
+  tmp = wave_min(tmp);
+  if ((threadIdx.x & 63) == 0) atomicMin(&a.result[1], (unsigned long long)__double_as_longlong(tmp));
+}
+int launch_dt_mp(const DtArgs &a, hipStream_t s)
+{
+  const long non = (long)a.g.ng[0] * a.g.ng[1] * a.g.ng[2];
+  long nb = (non + 255) / 256;
+  if (nb > 2048) nb = 2048;   // grid-stride, eight blocks per CU: the tables are staged once per block
+  hipLaunchKernelGGL(k_dt_mp, dim3((unsigned)nb), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 int launch_dt(const DtArgs &a, hipStream_t s)
 {
   const long non = (long)a.g.ng[0] * a.g.ng[1] * a.g.ng[2];

@@ -472,6 +472,8 @@ struct Handle {
   double *ddE = nullptr;  // cooling source per cell (k_cooling_dE -> k_stage_rows2)
   bool fuse_dt = true;    // PION_FUSE_DT=0: always run k_dt (A/B)
   bool uneven_chunks = true;   // PION_UNEVEN_CHUNKS=0: equal plane chunks (A/B)
+  bool dt_mp_pending = false;  // k_dt_mp owed after the two streams of a split stage have joined
+  bool split_dt_mp = true;     // PION_SPLIT_DT_MP=0: cooling time inside the stage kernel's fused reduction (A/B)
   bool fuse_bc = true;    // PION_FUSE_BC=0: periodic faces one launch per face (A/B)
 };
 
@@ -614,6 +616,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   if (const char *e = getenv("PION_FUSE_DT")) h->fuse_dt = (atoi(e) != 0);
   if (const char *e = getenv("PION_FUSE_BC")) h->fuse_bc = (atoi(e) != 0);
   if (const char *e = getenv("PION_UNEVEN_CHUNKS")) h->uneven_chunks = (atoi(e) != 0);
+  if (const char *e = getenv("PION_SPLIT_DT_MP")) h->split_dt_mp = (atoi(e) != 0);
   if (const char *e = getenv("PION_ROWS")) h->rows = h->rows1 = (atoi(e) >= 1 && atoi(e) <= 64) ? atoi(e) : 0;
   if (const char *e = getenv("PION_ROWS1")) h->rows1 = (atoi(e) >= 1 && atoi(e) <= 8) ? atoi(e) : 0;
   if (const char *e = getenv("PION_ZCHUNK")) h->zchunk = atoi(e) > 0 ? atoi(e) : 0;
@@ -850,6 +853,7 @@ int pion_gpu_upload(void *handle, const double *P_soa)
   h->ph_valid = false;
   h->dt_cached = false;
   h->dt_requested = false;   // a read-back requested for the previous state is void
+  h->dt_mp_pending = false;
   return 0;
 }
 
@@ -1261,6 +1265,33 @@ static bool stage_can_split(const Handle *h)
          && h->g.ng[2] > 2 * h->g.nbc[2] && !(h->cfg.tm_ooa == 1 && h->cfg.sp_ooa == 1);
 }
 
+// min of the cooling time over the state the full step has just written (P), into ddt[1]: k_dt_mp
+static int launch_cooling_time(Handle *h, hipStream_t s)
+{
+  const pion_gpu_config &cfg = h->cfg;
+  DtArgs d;
+  d.g = h->g;
+  d.P = h->dP;
+  d.Ph = h->dP;
+  d.flags = h->dflags;
+  d.result = h->ddt;
+  d.errword = h->derr;
+  d.eqntype = cfg.eqntype;
+  d.nvar = cfg.nvar;
+  d.gamma = cfg.gamma;
+  d.cfl = cfg.cfl;
+  d.do_mp = 1;
+  d.cool = h->cool;
+  time_begin(h, 3);
+  const int rc = cfg.strict_fp ? fp_strict::launch_dt_mp(d, s) : fp_fast::launch_dt_mp(d, s);
+  time_end(h, 3);
+  if (rc != 0) {
+    h->err = "cooling-time kernel launch failed";
+    return PION_GPU_EDEVICE;
+  }
+  return 0;
+}
+
 // planes [kz0,kz1) and, if kz3 > kz2, also [kz2,kz3) (the two z-boundary strips go out as ONE launch)
 static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_step, int kz0, int kz1,
                         bool first, bool last, int kz2 = 0, int kz3 = 0, hipStream_t ls = 0, bool use_ls = false)
@@ -1449,7 +1480,10 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
                        && ((h->g.ndim == 3 && h->g.nbc[2] >= 2) || h->g.ndim == 2) && a.out == h->dP;
   a.dtres = nullptr;
   a.cfl = cfg.cfl;
-  a.dt_mp = mp_dt_limited(cfg) ? 1 : 0;
+  // the cooling time: not in the stage kernel's fused reduction but in its own launch behind the last part of the
+  // stage (k_dt_mp, rate tables in LDS; PION_SPLIT_DT_MP=0: fused, A/B)
+  const bool split_mp = fuse_dt && mp_dt_limited(cfg) && h->split_dt_mp;
+  a.dt_mp = (mp_dt_limited(cfg) && !split_mp) ? 1 : 0;
   h->dt_cached = false;
   if (fuse_dt) {
     if (first)
@@ -1472,6 +1506,12 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     return PION_GPU_EDEVICE;
   }
   if (!last) return 0;
+  if (split_mp) {
+    // (a part launched on the side stream runs beside the interior part: the launch then follows where the compute
+    // stream has joined both, pion_gpu_stage_part)
+    if (use_ls) h->dt_mp_pending = true;
+    else if (int rc2 = launch_cooling_time(h, ls)) return rc2;
+  }
   if (is_full_step && a.out == h->dPh) {
     // OA1/OA1: copy the result back to P ("P = Ph", time_integrator.cpp:938-939)
     const size_t nb = sizeof(double) * (size_t)cfg.nvar * h->g.ncell;
@@ -1511,6 +1551,10 @@ int pion_gpu_stage_part(void *handle, double dt_stage, int space_ooa, int is_ful
     if (rc) return rc;
     HCHECK(h, hipEventRecord(h->ev_bdone, h->bstream));
     HCHECK(h, hipStreamWaitEvent(h->stream, h->ev_bdone, 0));
+    if (h->dt_mp_pending) {
+      h->dt_mp_pending = false;
+      if (int rc2 = launch_cooling_time(h, h->stream)) return rc2;
+    }
     return order_after_unpack(h);
   }
   h->ev_pre_valid = false;

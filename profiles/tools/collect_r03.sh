@@ -12,8 +12,8 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity-build"
-prof() { tag=$1; shift; echo "== stats $tag"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r03_$tag -- $B "$@" > $OUT/prof_r03_$tag.log 2>&1 || { echo "FAILED stats $tag"; tail -3 $OUT/prof_r03_$tag.log; }; }
-pmc() { tag=$1; ctrs=$2; shift; shift; echo "== pmc $tag"; rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/pmc_r03_$tag -- $B "$@" > $OUT/pmc_r03_$tag.log 2>&1 || { echo "FAILED pmc $tag"; tail -3 $OUT/pmc_r03_$tag.log; }; }
+prof() { local tag=$1; shift; echo "== stats $tag"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r03_$tag -- $B "$@" > $OUT/prof_r03_$tag.log 2>&1 || { echo "FAILED stats $tag"; tail -3 $OUT/prof_r03_$tag.log; }; }
+pmc() { local tag=$1; local ctrs=$2; shift; shift; echo "== pmc $tag"; rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $OUT/pmc_r03_$tag -- $B "$@" > $OUT/pmc_r03_$tag.log 2>&1 || { echo "FAILED pmc $tag"; tail -3 $OUT/pmc_r03_$tag.log; }; }
 SQ="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD"
 prof m1
 prof mhd8 --eqn mhd
@@ -22,21 +22,20 @@ prof m3 --workload m3 --grid 256
 prof dmr2d --workload dmr2d --grid 4096
 prof mhd2d --workload mhd2d --grid 4096
 for wl in "m1" "m2 --workload m2" "m3 --workload m3 --grid 256" "dmr2d --workload dmr2d --grid 4096" "mhd2d --workload mhd2d --grid 4096"; do
-  set -- $wl; tag=$1; shift
-  pmc ${tag}_fetch "FETCH_SIZE" "$@"
-  pmc ${tag}_write "WRITE_SIZE" "$@"
-  pmc ${tag}_sq "$SQ" "$@"
+  set -- $wl; w=$1; shift
+  pmc ${w}_fetch "FETCH_SIZE" "$@"
+  pmc ${w}_write "WRITE_SIZE" "$@"
+  pmc ${w}_sq "$SQ" "$@"
 done
 pmc m1_rdreq "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum"
 pmc m1_l2 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
 pmc m1_wrreq "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum"
 pmc m1_clk "GRBM_GUI_ACTIVE GRBM_COUNT"
-if [ ! -x $ROOT/profiles/tools/calib_traffic ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $ROOT/profiles/tools/calib_traffic $ROOT/profiles/tools/calib_traffic.hip
-fi
+# (always rebuilt: a binary of an earlier round may be lying in the tree)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o $ROOT/profiles/tools/calib_traffic $ROOT/profiles/tools/calib_traffic.hip 2>/dev/null
 for c in "fetch FETCH_SIZE" "write WRITE_SIZE" "rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum"; do
-  set -- $c; tag=$1; shift
-  echo "== calib $tag"; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_r03_calib_$tag -- $ROOT/profiles/tools/calib_traffic > $OUT/pmc_r03_calib_$tag.log 2>&1 || echo "FAILED calib $tag"
+  set -- $c; ct=$1; shift
+  echo "== calib $ct"; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_r03_calib_$ct -- $ROOT/profiles/tools/calib_traffic > $OUT/pmc_r03_calib_$ct.log 2>&1 || echo "FAILED calib $ct"
 done
 echo "collection done"
 python3 $ROOT/profiles/tools/summarize_r03.py
