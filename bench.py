@@ -133,7 +133,7 @@ def cpu_baseline(n, eqn, budget_s=10.0):
                    run as C independent periodic slabs (no halo exchange between them: an upper bound on an MPI
                    run of the same decomposition); sum of the processes' rates
       single_core  the same problem, n^3, one process
-      m2 / m3      single-core rates of the other two workloads at 48^3 (m3: cooling tables are not in
+      m2 / m3      single-core rates of the other two workloads at 48^3 (m3: the stellar-wind source is not in
                    oracle/_ref -- GSL -- so that one is the oracle, kind "port")
     kind "reference": oracle/_ref/libpion_ref.so (the reference's own solver objects, -O3 -DSERIAL, under
     oracle/ref_harness.cpp's time_integrator loops) when it is present, else kind "port": oracle/liboracle.so."""
@@ -176,7 +176,7 @@ def cpu_baseline(n, eqn, budget_s=10.0):
         out["m2_single_core"] = {"value": rate(singles[2]), "kind": out["kind"], "sample": "M2 Euler Roe-CV octant blast 48^3"}
     if singles[3]:
         out["m3_single_core"] = {"value": rate(singles[3]), "kind": "port",
-                                 "sample": "M3 Wind3D FVS + cooling 48^3 (oracle: cooling tables are parity-unpinned)"}
+                                 "sample": "M3 Wind3D FVS + cooling 48^3 (oracle: the stellar-wind source is not in oracle/_ref)"}
     return out
 
 
