@@ -551,7 +551,10 @@ def main():
                                    % ("GLM-MHD (nvar 9)" if eq == abi.EQGLM else "ideal MHD (nvar 8)", n),
                        "grid": [int(v) for v in cfg_g.ng[:3]], "nvar": nvar, "decomposition": "z-slab x%d" % world, "transport": ("RCCL send/recv to self (loopback)" if loopback else "none" if world == 1 else
                                      ((transport_note[0] + ": pinned host buffers + POSIX shared memory" if transport_note else "RCCL P2P") if args.backend == "nccl" else "gloo via pinned host buffers (rehearsal)"))
-                       + ("; time loop and transport issued from C++ (libpion_host)" if hs is not None else "; Python driver"),
+                       + ("; time loop and transport issued from C++ (libpion_host)" if hs is not None else "; Python driver")
+                       + ("; NOTE: RCCL transfers between two different GPUs were never exercised in development (one-GPU boxes; "
+                          "tests/test_gpu_host_two_ranks.py covers them where two devices exist) -- `--transport shm` (host-staged) "
+                          "and `--transport torch` are the verified fall-backs" if (world > 1 and not transport_note and hs is not None) else ""),
                        "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,

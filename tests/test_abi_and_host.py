@@ -31,6 +31,22 @@ def test_library_exports_every_declared_symbol():
     assert sorted(lib.EXPORTED_SYMBOLS) == syms
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/pion_host.h (the C view of pion_amd/host/) against libpion_host.so"""
+    host = os.path.join(ROOT, "pion_amd", "host", "libpion_host.so")
+    if not os.path.exists(host):
+        pytest.skip("libpion_host.so not built (run __graft_entry__.build())")
+    txt = open(os.path.join(ROOT, "include", "pion_host.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(pion_(?:host|backend)_[a-z_0-9]+)\s*\(", txt)))
+    assert len(syms) >= 25 and "pion_backend_gpu" in syms
+    abi.share_torch_hip_runtime()
+    C.CDLL(abi.library_path(), mode=C.RTLD_GLOBAL)
+    h = C.CDLL(host)
+    for s_ in syms:
+        assert hasattr(h, s_), "missing export " + s_
+
+
 def test_config_struct_matches_header():
     """Field order/size of the ctypes mirror against the C header (parsed textually)."""
     txt = open(os.path.join(ROOT, "include", "pion_gpu.h")).read()
