@@ -422,11 +422,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           }
           if (oa2) {
             double C[NV], sB[NV];
-#ifdef PION_EXP_NOC
-            load_rot2<NV, MHD>(St, ncb, 1, shb + 1 * syb, off, C);   // TIMING EXPERIMENT ONLY (wrong results): row +1 again
-#else
             load_rot2<NV, MHD>(St, ncb, 1, shb + 2 * syb, off, C);
-#endif
             if (lower) {
               // the slope of row j-1 (an upper face finds its row's slope carried in ysn)
               double M[NV];
@@ -483,11 +479,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
           to_sweep<NV, MHD>(2, q0, zq0);
           if (oa2) {
             double qp2[NV], sn[NV];
-#ifdef PION_EXP_NOQP2
-            load_rot2<NV, MHD>(St, ncb, 2, 1 * szb, off, qp2);   // TIMING EXPERIMENT ONLY (wrong results): plane k+1 again
-#else
             load_rot2<NV, MHD>(St, ncb, 2, 2 * szb, off, qp2);
-#endif
             hslope3<NV>(zq0, qp1, qp2, dx, thr, sn);
 #pragma unroll
             for (int v = 0; v < NV; v++) eR[v] = qp1[v] - sn[v] * 0.5;
