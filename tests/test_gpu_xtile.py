@@ -150,3 +150,30 @@ def test_2d_rows_per_wavefront_and_cell_kernel_agree(case, rows, monkeypatch):
     for A, t in out[1:]:
         assert t == out[0][1]
         assert np.array_equal(A, out[0][0])
+
+
+# ---- production-sized launches: many x tiles + the remainder tile, uneven plane chunks, every XCD's share of tiles ----
+@pytest.mark.parametrize("case,ng", [("glm_hlld", [200, 140, 150]), ("hd_roe", [330, 70, 100]), ("glm_hlld", [2048, 630]),
+                                     ("hd_fvs_tr", [1000, 333])], ids=["glm3d", "hd3d", "glm2d", "hdtr2d"])
+def test_rows_kernel_equals_cell_kernel_on_large_grids(case, ng, monkeypatch):
+    """the rows kernel (3-D: uneven chunks, per-XCD tile map; 2-D: rows marched along y) against the cell-per-thread
+    kernel on grids with hundreds of thousands of wavefront tiles, strict build: bit for bit after three steps, and
+    the time steps of the fused reduction equal to k_dt's"""
+    out = []
+    for env in ({}, {"PION_STAGE_KERNEL": "cell", "PION_ROWS_2D": "0"}):
+        for k in ("PION_STAGE_KERNEL", "PION_ROWS_2D"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg, P = _case(case, ng, 1)
+        with _gpu(cfg) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            dts = []
+            for _ in range(3):
+                dts.append(sc.calculate_timestep())
+                sc.advance_time()
+            out.append((g.download(0), dts))
+        del P
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0])
