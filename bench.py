@@ -353,7 +353,7 @@ def main():
         dev = local_rank % ngpu
         if world > 1 and (use_shm or ngpu < world):
             # host-staged transport: ranks agree on a shared-memory name through the bootstrap group
-            box = ["/pion_bench_%d" % os.getpid() if rank == 0 else None]
+            box = ["/pion_bench_%d_%d" % (os.getpid(), time.time_ns() % 1000000007) if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             transport_note.append("shm")
             h = host_rccl.HostSim(cfg, dev, rank=rank, world=world, periodic_z=periodic_z, shm_name=box[0])
@@ -378,7 +378,7 @@ def main():
             if not all(oks):
                 if h is not None:
                     h.close()
-                box = ["/pion_bench_%d" % os.getpid() if rank == 0 else None]
+                box = ["/pion_bench_%d_%d" % (os.getpid(), time.time_ns() % 1000000007) if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 transport_note.append("shm (fall-back: no RCCL communicator)")
                 h = host_rccl.HostSim(cfg, dev, rank=rank, world=world, periodic_z=periodic_z, shm_name=box[0])

@@ -100,7 +100,8 @@ def _run(case, transport, token):
 
 @pytest.mark.parametrize("case", ["glm_periodic", "hd_octant", "wind3d"])
 def test_cpp_loop_two_ranks_one_gpu_shared_memory_transport(case):
-    _run(case, "shm", "/pion_g%d_%s" % (os.getpid(), case))
+    import time
+    _run(case, "shm", "/pion_g%d_%d_%s" % (os.getpid(), time.time_ns() % 1000000007, case))
 
 
 def _ngpu():

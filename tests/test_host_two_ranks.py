@@ -89,7 +89,8 @@ def test_cpp_time_loop_two_ranks_over_shared_memory(case):
         ref, tref = o.download(0), sc.simtime
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    name = "/pion_t%d_%s" % (os.getpid(), case)
+    import time
+    name = "/pion_t%d_%d_%s" % (os.getpid(), time.time_ns() % 1000000007, case)
     procs = [ctx.Process(target=_worker, args=(r, 2, name, case, nsteps, q)) for r in range(2)]
     for p in procs:
         p.start()
