@@ -72,8 +72,10 @@ def _worker(rank, world, name, case, nsteps, q):
         q.put((rank, None, repr(e)))
 
 
-@pytest.mark.parametrize("case", ["glm_periodic", "hd_octant", "wind3d"])
-def test_cpp_time_loop_two_ranks_over_shared_memory(case):
+@pytest.mark.parametrize("case,world", [("glm_periodic", 2), ("hd_octant", 2), ("wind3d", 2), ("glm_periodic", 4), ("hd_octant", 3)])
+def test_cpp_time_loop_two_ranks_over_shared_memory(case, world):
+    """world = 2: both neighbours of a periodic rank are the same peer; world = 3 / 4: middle ranks with two different
+    neighbours, end ranks with one (hd_octant) or the periodic wrap (glm_periodic)"""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from cpu_backends import CpuSim
@@ -91,19 +93,19 @@ def test_cpp_time_loop_two_ranks_over_shared_memory(case):
     q = ctx.Queue()
     import time
     name = "/pion_t%d_%d_%s" % (os.getpid(), time.time_ns() % 1000000007, case)
-    procs = [ctx.Process(target=_worker, args=(r, 2, name, case, nsteps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, name, case, nsteps, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
-    for _ in range(2):
+    for _ in range(world):
         r, t, A = q.get(timeout=300)
         assert t is not None, A
         res[r] = (t, A)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    nb, nzl = cfg.nbc, cfg.ng[2] // 2
-    for r in range(2):
+    nb, nzl = cfg.nbc, cfg.ng[2] // world
+    for r in range(world):
         t, A = res[r]
         assert t == tref
         got = A[:, nb:nb + nzl]
