@@ -20,14 +20,28 @@ namespace pion {
 struct Cooling {
   static PDEV double edot(const CoolDev &c, const double rho, const double T)
   {
-    int ihi = c.NT - 1, ilo = 0, imid = 0;
-    do {
-      imid = ilo + (int)floor((ihi - ilo) / 2.0);
-      if (c.T[imid] < T) ilo = imid;
-      else ihi = imid;
-    } while (ihi - ilo > 1);
-    const int iT = ilo;
     const int NT = c.NT;
+    // The table interval: the reference bisects (mp_only_cooling.cpp:496-503), which ends on the largest i in
+    // [0, NT-2] with T[i] < T (0 if there is none; NaN -> 0).  On the log-spaced grid the same i comes from a
+    // single-precision logarithm as a first guess, corrected by stepping along the table itself until exactly that
+    // condition holds: the same index for every T, bit-identical results, an eighth of the dependent look-ups.
+    int ilo = 0;
+    if (c.inv_dlg > 0.0f) {
+      float gi = (T > 0.0) ? (__log2f((float)T) - c.lg0) * c.inv_dlg : 0.0f;
+      gi = fminf(fmaxf(gi, 0.0f), (float)(NT - 2));
+      ilo = (int)gi;
+      while (ilo > 0 && !(c.T[ilo] < T)) ilo--;
+      while (ilo < NT - 2 && c.T[ilo + 1] < T) ilo++;
+    }
+    else {
+      int ihi = NT - 1, imid = 0;
+      do {
+        imid = ilo + (int)floor((ihi - ilo) / 2.0);
+        if (c.T[imid] < T) ilo = imid;
+        else ihi = imid;
+      } while (ihi - ilo > 1);
+    }
+    const int iT = ilo;
     const double dT = T - c.T[iT];
     const double rho2 = rho * rho;
     double rate = 0.0;

@@ -36,6 +36,9 @@ struct CoolDev {
   const double *slope;   // [5][NT]
   double inv_Mu2, inv_Mu2_elec_H, Mu_tot_over_kB;
   double MinT_allowed, MaxT_allowed;
+  // log-spaced temperature grid (what gen_mpoc_lookup_tables builds): first guess of the table interval,
+  // (log2 T - lg0) * inv_dlg, corrected against the table itself; inv_dlg = 0: not log-spaced, bisect
+  float lg0, inv_dlg;
 };
 
 // Uneven plane chunks of a strip of np planes: chunk number cz covers [*k0, *k1) (relative to the strip); returns the

@@ -1014,6 +1014,26 @@ int pion_gpu_set_cooling_tables(void *handle, int nT, const double *T, const dou
   HCHECK(h, hipMemcpy(h->dcoolT, T, sizeof(double) * nT, hipMemcpyHostToDevice));
   HCHECK(h, hipMemcpy(h->dcooltab, tabs, sizeof(double) * 5 * nT, hipMemcpyHostToDevice));
   HCHECK(h, hipMemcpy(h->dcoolslope, slopes, sizeof(double) * 5 * nT, hipMemcpyHostToDevice));
+  // log-spaced grid?  (mp_only_cooling's is: T_i = 10^(log10 Tmin + i dlogT), mp_only_cooling.cpp:533-537.)  Then the
+  // device finds the table interval from a single-precision logarithm instead of bisecting; the guess only has to
+  // land within a few entries of the truth -- it is corrected against the table -- so a loose check suffices.
+  h->cool.lg0 = 0.0f;
+  h->cool.inv_dlg = 0.0f;
+  if (T[0] > 0.0 && T[nT - 1] > T[0]) {
+    const double l0 = log2(T[0]), inv = (nT - 1) / (log2(T[nT - 1]) - l0);
+    bool ok = true;
+    for (int i = 0; i < nT && ok; i++) {
+      if (!(T[i] > 0.0) || (i > 0 && !(T[i] > T[i - 1]))) ok = false;
+      else if (fabs((log2(T[i]) - l0) * inv - i) > 0.25) ok = false;
+    }
+    if (ok) {
+      h->cool.lg0 = (float)l0;
+      h->cool.inv_dlg = (float)inv;
+    }
+  }
+  if (const char *e = getenv("PION_COOL_BISECT")) {
+    if (atoi(e) != 0) h->cool.inv_dlg = 0.0f;   // A/B and cross-check: the reference's bisection
+  }
   h->cool.NT = nT;
   h->cool.T = h->dcoolT;
   h->cool.tab = h->dcooltab;

@@ -78,3 +78,45 @@ def test_cooling_tables_size_is_checked():
         T = np.logspace(1, 9, n)
         with pytest.raises(Exception):
             g.set_cooling_tables(T, np.ones((5, n)), np.zeros((5, n)))
+
+
+def test_table_interval_from_the_log_guess_equals_the_bisection(monkeypatch):
+    """Edot's table interval: the reference bisects; on the log-spaced grid the device starts from a single-precision
+    logarithm and corrects against the table (same index by construction).  Bit-identical to the bisecting path
+    (PION_COOL_BISECT=1) and to the oracle at table nodes, one ulp either side of them, outside the table, and for a
+    table that is NOT log-spaced (where the device falls back to bisecting)."""
+    cfg, P, _, _ = _wind_cfg(1)
+    T, tabs, sl = cooling.build_tables(cfg.min_temp, cfg.max_temp)
+    rng = np.random.default_rng(11)
+    n = 6000
+    rho = 10.0 ** rng.uniform(-26, -20, n)
+    Tk = 10.0 ** rng.uniform(2.5, 9.0, n)
+    k = rng.integers(0, T.size, 600)
+    Tk[:200] = T[k[:200]]
+    Tk[200:400] = np.nextafter(T[k[200:400]], 0.0)
+    Tk[400:600] = np.nextafter(T[k[400:600]], np.inf)
+    Tk[600:610] = [T[0], T[-1], np.nextafter(T[0], 0), np.nextafter(T[-1], np.inf), 1e-30, 1e30, 1e300, 1e-300, 5e-324, T[1]]
+    out = {}
+    for mode in ("log", "bisect"):
+        if mode == "bisect":
+            monkeypatch.setenv("PION_COOL_BISECT", "1")
+        else:
+            monkeypatch.delenv("PION_COOL_BISECT", raising=False)
+        with _gpu(cfg) as g:
+            g.set_cooling_tables(T, tabs, sl)
+            out[mode] = g.cooling_edot(rho, Tk)
+    monkeypatch.delenv("PION_COOL_BISECT", raising=False)
+    with _cpu(cfg) as o:
+        o.set_cooling_tables(T, tabs, sl)
+        want = o.cooling_edot(rho, Tk)
+    assert np.array_equal(out["log"], out["bisect"])
+    assert np.array_equal(out["log"], want)
+    # a linearly spaced table: not log-spaced -> bisection on the device; still the oracle's answer
+    Tl = np.linspace(5.0e3, 1.0e8, 200)
+    tl = np.abs(rng.normal(1e-23, 3e-24, (5, 200)))
+    sll = np.zeros((5, 200))
+    sll[:, :-1] = np.diff(tl, axis=1) / np.diff(Tl)
+    with _gpu(cfg) as g, _cpu(cfg) as o:
+        g.set_cooling_tables(Tl, tl, sll)
+        o.set_cooling_tables(Tl, tl, sll)
+        assert np.array_equal(g.cooling_edot(rho, Tk), o.cooling_edot(rho, Tk))
