@@ -236,6 +236,53 @@ class _stdout_to_stderr:
         return False
 
 
+def exchange_digests(A, nbc_z, nz):
+    """hashes of the four z plane groups of one rank's state array A[nvar][nz + 2 nbc][ny + 2 nbc][nx + 2 nbc]"""
+    import hashlib
+
+    def dig(x):
+        return hashlib.blake2b(np.ascontiguousarray(x).tobytes(), digest_size=16).hexdigest()
+    nb = int(nbc_z)
+    return {"ghost_lo": dig(A[:, 0:nb]), "own_lo": dig(A[:, nb:2 * nb]),
+            "own_hi": dig(A[:, nz:nz + nb]), "ghost_hi": dig(A[:, nz + nb:nz + 2 * nb]),
+            "finite": bool(np.isfinite(A).all())}
+
+
+def compare_exchange(every, periodic_z):
+    """every[r] = exchange_digests of rank r; returns the list of faces whose ghosts are not the neighbour's planes"""
+    world = len(every)
+    bad = []
+    for r in range(world):
+        lo, hi = r - 1, r + 1
+        if periodic_z:
+            lo, hi = lo % world, hi % world
+        if lo >= 0 and every[r]["ghost_lo"] != every[lo]["own_hi"]:
+            bad.append("rank %d lower ghosts != rank %d top planes" % (r, lo))
+        if hi < world and every[r]["ghost_hi"] != every[hi]["own_lo"]:
+            bad.append("rank %d upper ghosts != rank %d bottom planes" % (r, hi))
+        if not every[r]["finite"]:
+            bad.append("rank %d holds non-finite values" % r)
+    return bad
+
+
+def check_exchange(sim, cfg, rank, world, periodic_z, dist):
+    """After the last step of an N > 1 run (untimed): every rank's z ghost planes must be, bit for bit, the planes its
+    neighbour owns -- whole planes, x / y ghost cells included, which is what the exchange moves.  Hashes of the four
+    plane groups of every rank go through the bootstrap group; rank 0 compares.  This is the check that the transport
+    moved the right data on THIS machine (development had one-GPU boxes only)."""
+    mine = exchange_digests(sim.download(0), int(cfg.nbc), int(cfg.ng[2]))
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    if rank != 0:
+        return None
+    bad = compare_exchange(every, periodic_z)
+    if bad:
+        sys.stderr.write("bench.py: EXCHANGE CHECK FAILED: %s\n" % "; ".join(bad))
+        return "FAILED: " + "; ".join(bad)
+    return "ok: after the last step every rank's z ghost planes equal its neighbours' owned planes bit for bit (%d faces)" % (
+        2 * world if periodic_z else 2 * (world - 1))
+
+
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2])
@@ -250,6 +297,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the launches with HIP events (A/B of the event overhead; roofline fields are 0)")
     ap.add_argument("--no-parity-build", action="store_true", help="skip the strict-build throughput run")
+    ap.add_argument("--no-exchange-check", action="store_true",
+                    help="N > 1: skip the untimed end-of-run check that every rank's z ghosts equal its neighbours' planes")
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="cells per axis of the all-cores CPU baseline sample (16 slabs of n x n x n/16; the single-process "
                          "samples use min(n, 128))")
@@ -492,6 +541,9 @@ def main():
             step()
         barrier()
         tm = sim.get_timing()
+    exchange_check = None
+    if world > 1 and not args.no_exchange_check:
+        exchange_check = check_exchange(sim, cfg, rank, world, periodic_z, dist)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device="cuda" if (args.backend == "nccl" and hs is None) else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -555,7 +607,8 @@ def main():
                        + ("; NOTE: RCCL transfers between two different GPUs were never exercised in development (one-GPU boxes; "
                           "tests/test_gpu_host_two_ranks.py covers them where two devices exist) -- `--transport shm` (host-staged) "
                           "and `--transport torch` are the verified fall-backs" if (world > 1 and not transport_note and hs is not None) else ""),
-                       "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)"},
+                       "fp_mode": "strict (no FMA)" if args.strict else "fast (FMA contraction)",
+                       "exchange_check": exchange_check},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling_6290GBs": achieved / 6290.0,
                          "step_frac": value * 1e6 * 5 * nvar * 8 / (HBM_PEAK_GBS * 1e9 * world),
