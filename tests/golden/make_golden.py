@@ -241,8 +241,42 @@ def main_e():
     print("shocktubes.npz", os.path.getsize(os.path.join(HERE, "shocktubes.npz")) // 1024, "KiB")
 
 
+def main_f():
+    """endstate_s.npz: more of the reference's shipped uniform-grid test problems (gc.END_CASES_S: FieldLoop x 3,
+    advection of a contact discontinuity, Liska-Wendroff implosion, oblique shocks M25 / M40 with three solver /
+    viscosity pairs, the axisymmetric blast waves in Euler and glm-mhd) run by the reference objects: every dt, the end
+    state, the conserved totals.  One child process per case (a failed Riemann solve ends the process).
+    `make_golden.py f [case]`."""
+    import subprocess
+    import time
+    if len(sys.argv) > 2:
+        name = sys.argv[2]
+        cfg, P, tf, nmax = gc.end_case_s(name)
+        with CpuSim(cfg, "ref") as r:
+            n, t, dts = gc.end_run(r, cfg, P, tf, nmax)
+            A = r.download(0)
+        tot, _ = gc.conserved_totals(cfg, A)
+        np.savez(os.path.join("/tmp", "es_%s.npz" % name), n=n, t=t, dt=dts, P=A, tot=tot)
+        return
+    out = {}
+    for name in gc.END_CASES_S:
+        t0 = time.time()
+        rc = subprocess.call([sys.executable, os.path.abspath(__file__), "f", name], stdout=subprocess.DEVNULL)
+        if rc != 0:
+            print("%-28s the reference gave up (exit %d): no fixture" % (name, rc))
+            continue
+        z = np.load(os.path.join("/tmp", "es_%s.npz" % name))
+        for k in ("n", "t", "dt", "P", "tot"):
+            out[name + "_" + k] = z[k]
+        print("%-28s %4d steps to t = %.6g  (%.1f s)" % (name, int(z["n"]), float(z["t"]), time.time() - t0))
+    np.savez_compressed(os.path.join(HERE, "endstate_s.npz"), **out)
+    print("endstate_s.npz", os.path.getsize(os.path.join(HERE, "endstate_s.npz")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "e":
+    if len(sys.argv) > 1 and sys.argv[1] == "f":
+        main_f()
+    elif len(sys.argv) > 1 and sys.argv[1] == "e":
         main_e()
     elif len(sys.argv) > 1 and sys.argv[1] == "d":
         main_d()
@@ -256,3 +290,4 @@ if __name__ == "__main__":
         main_c()
         main_d()
         main_e()
+        main_f()

@@ -429,3 +429,158 @@ def shock_tube_case(name, strict_fp=1, nx=200):
     for v in range(cfg.nvar):
         P[v] = np.where(X < xm, L[v], R[v])
     return cfg, P, tf
+
+
+# ---- more of the reference's shipped uniform-grid test problems (endstate_s.npz, `make_golden.py f`) ----------------
+# Parameter files under /root/reference/test_problems/, initial conditions restated from source/ics/ (file:line in
+# each case); run by the reference's solver objects to the shipped finish time or a step cap (CPU seconds).
+END_CASES_S = ["fieldloop100", "fieldloop100_vz", "fieldloop100_static", "advection_cd3_n128", "lwi_n064",
+               "oblique_m25_roe_fkj", "oblique_m25_roe_hcorr", "oblique_m25_fvs_fkj", "oblique_m40_roe_hcorr",
+               "bwaxi2d_halfplane_nr016", "mhdbwaxi2d_halfplane_nr032"]
+
+
+def _oblique(mach, solver, artvisc, strict_fp):
+    # test_problems/ObliqueShock/params_oblique_shock_M25.txt / _M40.txt: 100 x 50 on [0,1e17] x [0,0.5e17], Euler +
+    # one tracer, gamma 5/3, XN outflow / XP fixed / YN, YP outflow; run_ObliqueShockTest.sh runs each with cfl 0.4,
+    # eta 0.1 and {Roe-CV + FKJ98, Roe-CV + H-correction, FVS + FKJ98}.  IC_shocktube::setup_data / assign_data
+    # (ics/shock_tube.cpp:60-356): STnumber <= 0 reads pre / post-shock vectors; BOTH tracer parameters land in the
+    # PRE-shock vector (:273-285), so the post-shock tracer stays 0 and the pre-shock one is STpostvecTR0 = -1;
+    # the states are rotated by STangleXY = 2 degrees (eqns_base::rotateXY) and the interface is the line
+    # x0(y) = shockpos + (0.5 - Ymin) tan(a) - (y - Ymin) tan(a), left (post-shock) state where x <= x0.
+    post = {25: (3.9808917197e-22, 7.81e-10, -8.2074451397e05), 40: None}
+    pre = {25: (1.0e-22, 1.0e-12, -3.237486122e6), 40: None}
+    if mach == 40:
+        # params_oblique_shock_M40.txt
+        post[40] = (3.9925140362e-22, 1.99975e-09, -1.2934150634e+06)
+        pre[40] = (1.0e-22, 1.0e-12, -5.1639777950e+06)
+    cfg = abi.make_config(2, [100, 50], abi.EQEUL, solver, ntracer=1, artvisc=artvisc, etav=0.1, gamma=1.666666666666666666,
+                          cfl=0.4, xmin=(0.0, 0.0, 0.0), xmax=(1.0e17, 0.5e17, 0.0),
+                          bcs=["outflow", "fixed", "outflow", "outflow"],
+                          refvec=[1.0e-22, 1.0e-10, 1.0e6, 1.0e6, 1.0e6, 1.0], strict_fp=strict_fp)
+    ang = 2.0 * np.pi / 180.0
+    ct, st, tt = np.cos(ang), np.sin(ang), np.tan(ang)
+
+    def rot(s):
+        ro, pg, vx = s
+        return (ro, pg, vx * ct, vx * st, 0.0)   # rotateXY of (vx, 0, 0)
+    left, right = rot(post[mach]) + (0.0,), rot(pre[mach]) + (-1.0,)
+    P = problems.alloc(cfg)
+    X, Y, _ = problems.mesh(cfg)
+    x0 = (4.0e16 + 0.5 * tt) - Y * tt
+    for v in range(cfg.nvar):
+        P[v] = np.where(X <= x0, left[v], right[v])
+    return cfg, P
+
+
+# params_MHDaxi2dBW_HalfPlane_NR128.txt: glm-mhd with the Roe solver (4), CFL 0.2, FKJ98 eta 0.15, 1e51 erg in
+# BW_nzones = 8 cells of the 256 x 128 grid (= 2 cells at 64 x 32), BWmagfieldX = 5.25357e-6 G along the axis
+_MHDBW = {"eq": abi.EQGLM, "solver": abi.FLUX_RSroe, "av": abi.AV_FKJ98_1D, "eta": 0.15, "cfl": 0.2,
+          "bcs": ["outflow", "outflow", "reflecting", "outflow"], "nzones": 2.0, "ro": 2.34e-22, "pg": 1.38e-11,
+          "energy": 1.0e51, "tf": 1.578e12}
+_MHDBW_BX = 5.25357e-06 / np.sqrt(4.0 * np.pi)
+
+
+def end_case_s(name, strict_fp=1):
+    """-> (cfg, P, finishtime, max_steps)"""
+    if name.startswith("fieldloop100"):
+        # test_problems/FieldLoop/params_FieldLoop100{,vz,Static}.txt: glm-mhd, HLLD (7), 100 x 50 on [-1,1] x [-1/2,1/2],
+        # periodic, CFL 0.4, FKJ98 eta 0.1, t = 2.  IC_basic_tests::setup_FieldLoop (ics/basic_tests.cpp:553-665):
+        # rho = p = 1, v = (2, 1, vz) (static: 0), A_z = 1e-3 (0.3 - r) inside r < 0.3, B = curl A by central
+        # differences (VectorOps_Cart::Curl, coord_sys/VectorOps.cpp:446-528)
+        vz = {"fieldloop100": 0.0, "fieldloop100_vz": 1.0, "fieldloop100_static": 0.0}[name]
+        vel = 0.0 if name.endswith("static") else 2.0
+        cfg = abi.make_config(2, [100, 50], abi.EQGLM, abi.FLUX_RS_HLLD, artvisc=abi.AV_FKJ98_1D, etav=0.1,
+                              gamma=5.0 / 3.0, cfl=0.4, xmin=(-1.0, -0.5, 0.0), xmax=(1.0, 0.5, 0.0), bcs=["periodic"] * 4,
+                              refvec=[1.0] * 9, strict_fp=strict_fp)
+        P = problems.alloc(cfg)
+        X, Y, _ = problems.mesh(cfg)
+        P[abi.RO] = 1.0
+        P[abi.PG] = 1.0
+        P[abi.VX] = vel
+        P[abi.VY] = vel / 2.0
+        P[abi.VZ] = vz
+        r = np.sqrt(X * X + Y * Y)
+        A = np.where(r < 0.3, 0.001 * (0.3 - r), 0.0)
+        # (the ghost cells hold no potential when the reference takes the curl; the loop does not reach them)
+        nb = cfg.nbc
+        A[:, :nb, :] = A[:, -nb:, :] = 0.0
+        A[:, :, :nb] = A[:, :, -nb:] = 0.0
+        Bx = np.zeros_like(A)
+        By = np.zeros_like(A)
+        Bx[:, 1:-1, :] = (A[:, 2:, :] - A[:, :-2, :]) / (2.0 * cfg.dx)
+        By[:, :, 1:-1] = -(A[:, :, 2:] - A[:, :, :-2]) / (2.0 * cfg.dx)
+        P[abi.BX], P[abi.BY] = Bx, By
+        return cfg, P, 2.0, {"fieldloop100": 2000, "fieldloop100_vz": 120, "fieldloop100_static": 120}[name]
+    if name == "advection_cd3_n128":
+        # test_problems/advection/params_advection_v020t30_l1n128.txt: StarBench_ContactDiscontinuity3 (ics/
+        # StarBench_test.cpp:156-300): Euler + one tracer, gamma 1.0001, Roe-CV (4), FKJ98 eta 0.15, CFL 0.4, 128^2 on
+        # [0,2]^2, periodic; a square of rho = 10 rotated by 1 radian about (1,1), p = 10, v = (1.78884, 0.89443)
+        cfg = abi.make_config(2, [128, 128], abi.EQEUL, abi.FLUX_RSroe, ntracer=1, artvisc=abi.AV_FKJ98_1D, etav=0.15,
+                              gamma=1.0001, cfl=0.4, xmin=(0.0, 0.0, 0.0), xmax=(2.0, 2.0, 0.0), bcs=["periodic"] * 4,
+                              refvec=[1.0] * 6, strict_fp=strict_fp)
+        P = problems.alloc(cfg)
+        X, Y, _ = problems.mesh(cfg)
+        tt = np.tan(1.0)
+        itt = 1.0 / tt
+        ifst = 1.0 / (4.0 * np.sin(1.0))
+        inside = ~((Y > 1.0 + itt + ifst - X * itt) | (Y < 1.0 + itt - ifst - X * itt)
+                   | (Y > tt * (X - (1.0 - itt - ifst))) | (Y < tt * (X - (1.0 - itt + ifst))))
+        P[abi.RO] = np.where(inside, 10.0, 1.0)
+        P[abi.PG] = 10.0
+        P[abi.VX] = 1.78884
+        P[abi.VY] = 0.89443
+        P[5] = np.where(inside, 1.0, 0.0)
+        return cfg, P, 2.2360679775, 150
+    if name == "lwi_n064":
+        # test_problems/LiskaWendroffImplosion/params_LWI_d2l1n400.txt at 64^2: Euler, gamma 1.4, Roe-CV (4), NO
+        # artificial viscosity, CFL 0.3, [0,0.3]^2, reflecting walls, t = 2.5; setup_LWImplosion
+        # (ics/basic_tests.cpp:923-954): rho = p = 1, (0.125, 0.14) below the diagonal x + y < 0.15
+        cfg = abi.make_config(2, [64, 64], abi.EQEUL, abi.FLUX_RSroe, artvisc=abi.AV_NONE, etav=0.15, gamma=1.4,
+                              cfl=0.3, xmin=(0.0, 0.0, 0.0), xmax=(0.3, 0.3, 0.0), bcs=["reflecting"] * 4,
+                              refvec=[1.0] * 5, strict_fp=strict_fp)
+        P = problems.alloc(cfg)
+        X, Y, _ = problems.mesh(cfg)
+        low = (X < 0.15) & (Y < (0.15 - X))
+        P[abi.RO] = np.where(low, 0.125, 1.0)
+        P[abi.PG] = np.where(low, 0.14, 1.0)
+        return cfg, P, 2.5, 400
+    if name.startswith("oblique_"):
+        mach = 25 if "_m25_" in name else 40
+        solver = abi.FLUX_FVS if "_fvs_" in name else abi.FLUX_RSroe
+        av = abi.AV_HCORRECTION if name.endswith("hcorr") else abi.AV_FKJ98_1D
+        cfg, P = _oblique(mach, solver, av, strict_fp)
+        return cfg, P, 9.48e10, 250
+    if name == "bwaxi2d_halfplane_nr016":
+        # test_problems/blastwave_axi2d/params_axi2dBW_HalfPlane_NR016.txt: cylindrical (z,R) 32 x 16, Euler, Roe-CV,
+        # FKJ98 0.1, CFL 0.3, outflow / reflecting axis / outflow, 1e51 erg in BW_nzones = 2 cells, t = 1.58e12;
+        # IC_blastwave::setup_cyl_bw (ics/blast_wave.cpp:555-615): cells whose centre is within the blast radius
+        L = 30.86e18
+        cfg = abi.make_config(2, [32, 16], abi.EQEUL, abi.FLUX_RSroe, artvisc=abi.AV_FKJ98_1D, etav=0.1,
+                              gamma=1.666666666666666666666, cfl=0.3, xmin=(-L, 0.0, 0.0), xmax=(L, L, 0.0),
+                              bcs=["outflow", "outflow", "reflecting", "outflow"],
+                              refvec=[1.0e-22, 3.0e-10, 1.0e6, 1.0e6, 1.0e6], strict_fp=strict_fp, coord_sys=2)
+        P = problems.alloc(cfg)
+        X, Y, _ = problems.mesh(cfg)
+        rb = 2.0 * cfg.dx
+        P[abi.RO] = 2.34e-22
+        P[abi.PG] = np.where(np.sqrt(X * X + Y * Y) <= rb, 3.0 * 1.0e51 * (cfg.gamma - 1.0) / (4.0 * np.pi * rb ** 3), 1.38e-11)
+        return cfg, P, 1.58e12, 400
+    if name == "mhdbwaxi2d_halfplane_nr032":
+        # test_problems/blastwave_axi2d/params_MHDaxi2dBW_HalfPlane_NR128.txt at 64 x 32: as above with glm-mhd,
+        # HLLD (7) and the shipped axial field (BWmagfieldX, converted as ics/blast_wave.cpp:118-120 does)
+        L = 30.86e18
+        bx = _MHDBW_BX
+        cfg = abi.make_config(2, [64, 32], _MHDBW["eq"], _MHDBW["solver"], artvisc=_MHDBW["av"], etav=_MHDBW["eta"],
+                              gamma=1.666666666666666666666, cfl=_MHDBW["cfl"], xmin=(-L, 0.0, 0.0), xmax=(L, L, 0.0),
+                              bcs=_MHDBW["bcs"], refvec=[1.0e-22, 3.0e-10, 1.0e6, 1.0e6, 1.0e6, 1.0e-5, 1.0e-5, 1.0e-5, 1.0][
+                                  :(9 if _MHDBW["eq"] == abi.EQGLM else 8)],
+                              strict_fp=strict_fp, coord_sys=2)
+        P = problems.alloc(cfg)
+        X, Y, _ = problems.mesh(cfg)
+        rb = _MHDBW["nzones"] * cfg.dx
+        P[abi.RO] = _MHDBW["ro"]
+        P[abi.PG] = np.where(np.sqrt(X * X + Y * Y) <= rb, 3.0 * _MHDBW["energy"] * (cfg.gamma - 1.0) / (4.0 * np.pi * rb ** 3),
+                             _MHDBW["pg"])
+        P[abi.BX] = bx
+        return cfg, P, _MHDBW["tf"], 300
+    raise KeyError(name)
