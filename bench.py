@@ -302,12 +302,13 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=256,
                     help="cells per axis of the all-cores CPU baseline sample (16 slabs of n x n x n/16; the single-process "
                          "samples use min(n, 128))")
-    ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3", "dmr2d", "mhd2d"],
+    ap.add_argument("--workload", default="m1", choices=["m1", "m2", "m3", "dmr2d", "mhd2d", "axi2d", "mhdaxi2d"],
                     help="m1 (default, the headline): MHD blast; m2: 3-D Euler Roe-CV octant Sedov blast (SURVEY 8d); "
                          "m3: Wind3D single level, FVS + cooling 8 + stellar wind (single GPU); dmr2d / mhd2d: BASELINE "
                          "configs 2 and 3 (2-D double Mach reflection, Euler Roe-CV, --grid = cells along x, ny = nx / 3.25; "
-                         "2-D GLM-MHD blast wave, HLLD, --grid = nx, ny = 1.5 nx), one GPU.  All but m1 are extra rows for "
-                         "DESIGN.md")
+                         "2-D GLM-MHD blast wave, HLLD, --grid = nx, ny = 1.5 nx), one GPU; axi2d / mhdaxi2d: axisymmetric (z,R) "
+                         "blast, Euler Roe-CV / GLM-MHD HLLD (SURVEY 8f-4; --grid = cells along z, nR = nz / 2), one GPU.  All "
+                         "but m1 are extra rows for DESIGN.md")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 transport: nccl (= RCCL over xGMI, one rank per GPU) or gloo with the halo staged "
                          "through pinned host buffers (rehearsal of the multi-rank path, ranks may share a GPU)")
@@ -458,11 +459,19 @@ def main():
         periodic_z = False
         hs, sim = make_sim(cfg, False)
         eq = cfg.eqntype
-    elif args.workload in ("dmr2d", "mhd2d"):
-        # BASELINE configs[1] / [2] on one GPU (2-D grids do not shard along z)
+    elif args.workload in ("dmr2d", "mhd2d", "axi2d", "mhdaxi2d"):
+        # BASELINE configs[1] / [2] on one GPU (2-D grids do not shard along z); SURVEY 8f-4: cylindrical (z,R) grids
         if world > 1:
             raise SystemExit("bench.py: the 2-D workloads run on one GPU")
-        if args.workload == "dmr2d":
+        if args.workload == "axi2d":
+            cfg, P = problems.blast_axi2d(n, abi.EQEUL, abi.FLUX_RSroe, strict_fp=args.strict)
+            wl_name = ("AXI2D: axisymmetric (z,R) blast %d x %d, Euler Roe-CV + FKJ98 0.1, outflow / axis, OA2/OA2"
+                       % (cfg.ng[0], cfg.ng[1]))
+        elif args.workload == "mhdaxi2d":
+            cfg, P = problems.blast_axi2d(n, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=args.strict)
+            wl_name = ("MHDAXI2D: axisymmetric (z,R) blast %d x %d, GLM-MHD HLLD + FKJ98 0.1, outflow / axis, OA2/OA2"
+                       % (cfg.ng[0], cfg.ng[1]))
+        elif args.workload == "dmr2d":
             cfg, P = problems.double_mach_reflection(n, strict_fp=args.strict)
             wl_name = ("DMR2D: double Mach reflection %d x %d, Euler Roe-CV + FKJ98 0.1, inflow/outflow/reflecting/DMR, "
                        "OA2/OA2" % (cfg.ng[0], cfg.ng[1]))
@@ -617,7 +626,9 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch that left L2 (PMC FETCH_SIZE + WRITE_SIZE, calibrated; profiles/r03_pmc_traffic.json; null when the kernel sources have changed since)",
                          "kernel": {"m1": "k_stage_rows2<GLM,0,HLLD>" if eq == abi.EQGLM else "k_stage_rows2<MHD,0,HLLD>",
                                     "m2": "k_stage_rows2<EUL,0,Roe-CV>", "m3": "k_stage_rows2<EUL,1,FVS>",
-                                    "dmr2d": "2-D stage kernel <EUL,0,Roe-CV>", "mhd2d": "2-D stage kernel <GLM,0,HLLD>"}[args.workload]
+                                    "dmr2d": "2-D stage kernel <EUL,0,Roe-CV>", "mhd2d": "2-D stage kernel <GLM,0,HLLD>",
+                                    "axi2d": "2-D cylindrical stage kernel <EUL,0,Roe-CV,CYL>",
+                                    "mhdaxi2d": "2-D cylindrical stage kernel <GLM,0,HLLD,CYL>"}[args.workload]
                                    + " (first-order + second-order instance, mean per launch)",
                          "kernel_ms": stage_ms, "kernel_ms_from": "HIP events over %d steps after the timed region" % ev_steps, "launches_per_stage": (tm["stage_n"] / (2.0 * ev_steps) if ev_steps else 0.0), "prepass_ms": tm["prepass_ms"], "bc_ms": tm["bc_ms"],
                          "dt_ms": tm["dt_ms"], "algorithmic_bytes_per_launch": alg_bytes, "issue": valu},

@@ -668,7 +668,7 @@ static int cooling_go(const StageArgs &a, hipStream_t s)
 template <int EQ, int NTR, int SOLVER>
 static int stage_go(const StageArgs &a, hipStream_t s)
 {
-  if (a.use_march != 0 && ((a.g.ndim == 3 && a.g.nbc[2] >= 2) || (a.g.ndim == 2 && a.g.cyl == 0 && a.g.nbc[1] >= 2)))
+  if (a.use_march != 0 && ((a.g.ndim == 3 && a.g.nbc[2] >= 2) || (a.g.ndim == 2 && a.g.cyl != 2 && a.g.nbc[1] >= 2)))
     return stage_rows2_go<EQ, NTR, SOLVER>(a, s);
   const int nbx = (a.g.ng[0] + 63) / 64, nby = (a.g.ng[1] + 3) / 4;
   const long ntiles = (long)nbx * nby * a.g.ng[2];

@@ -649,7 +649,7 @@ int pion_gpu_create(const pion_gpu_config *cfg, int device, void **handle)
   // cell": grids of 2^29 cells or more (ghosts included) use the cell-per-thread kernel with 64-bit addresses
   // (2-D Cartesian grids run it without the z part; PION_ROWS_2D=0 puts them back on the cell-per-thread kernel)
   const bool rows3d = (g.ndim == 3 && g.nbc[2] >= 2);
-  bool rows2d = (g.ndim == 2 && g.cyl == 0 && g.nbc[1] >= 2 && g.nbc[0] >= 2);
+  bool rows2d = (g.ndim == 2 && g.cyl != 2 && g.nbc[1] >= 2 && g.nbc[0] >= 2);   // (cyl == 1: the CYL instance)
   if (const char *e = getenv("PION_ROWS_2D")) rows2d = rows2d && (atoi(e) != 0);
   if (!((rows3d || rows2d) && (unsigned long long)g.ncell * 8ull < (1ull << 32))) h->use_march = 0;
 

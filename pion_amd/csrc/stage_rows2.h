@@ -87,6 +87,91 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
   }
 }
 
+// SetSlope along R of a cylindrical grid (VectorOps_Cyl::SetSlope, VectorOps.cpp:1103-1204): the TRUE slope (not
+// x dx) from the differences of the cells' centres of mass cm, c0, cp
+template <int NV>
+PDEV void cyl_slope3(const double *qm, const double *q0, const double *qp, const double cm, const double c0, const double cp,
+                     const bool oa2, double *s)
+{
+#pragma unroll
+  for (int v = 0; v < NV; v++) s[v] = oa2 ? avg_falle((q0[v] - qm[v]) / (c0 - cm), (qp[v] - q0[v]) / (cp - c0)) : 0.0;
+}
+// The R axis of a cylindrical grid for one cell, in the sweep frame: MHD source of both faces, R-weighted flux
+// divergence and geometric source -- the statements of k_stage's cylR branch in the same order
+// (cyl_FV_solver_mhd_ideal_adi::MHDsource, solver_eqn_mhd_adi.cpp:1081-1092; VectorOps_Cyl::DivStateVectorComponent,
+// VectorOps.cpp:1211-1245; geometric_source, solver_eqn_hydro_adi.cpp:560-590, solver_eqn_mhd_adi.cpp:1001-1030,
+// 1175-1210).  Rm1 / R0: centres of the lower neighbour and of this cell; s0: this cell's slope along R.
+template <int EQ, int NV>
+PDEV void apply_axis_cyl(double *d, const double *q0, const double bnm, const double sim, const double bnp, const double sip,
+                         const double *Fm, const double *Fp, const double *s0, const double dt, const double dx,
+                         const double Rm1, const double R0, const bool oa2, const double chyp)
+{
+  constexpr bool MHD = (EQ != EQEUL);
+  if constexpr (MHD) {
+    const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
+    const double bm0 = 0.5 * (bnm + q0[qBN]);
+    {
+      double rp = Rm1 + dx * 0.5;
+      const double rn = rp;
+      rp += dx;
+      d[uMN] += dt * bm0 * (q0[qBN]) * 2.0 * rn / (rp * rp - rn * rn);
+      d[uMT1] += dt * bm0 * (q0[qBT1]) * 2.0 * rn / (rp * rp - rn * rn);
+      d[uMT2] += dt * bm0 * (q0[qBT2]) * 2.0 * rn / (rp * rp - rn * rn);
+      d[uERG] += dt * bm0 * (uB) * 2.0 * rn / (rp * rp - rn * rn);
+      d[uBN] += dt * bm0 * (q0[qVN]) * 2.0 * rn / (rp * rp - rn * rn);
+      d[uBT1] += dt * bm0 * (q0[qVT1]) * 2.0 * rn / (rp * rp - rn * rn);
+      d[uBT2] += dt * bm0 * (q0[qVT2]) * 2.0 * rn / (rp * rp - rn * rn);
+    }
+    if constexpr (EQ == EQGLM) {
+      const double sm0 = 0.5 * (sim + q0[qSI]);
+      d[uERG] += dt * sm0 * (q0[qVN] * q0[qSI]) / dx;
+      d[uPSI] += dt * sm0 * q0[qVN] / dx;
+    }
+    const double bm1 = 0.5 * (q0[qBN] + bnp);
+    {
+      const double rp = R0 + dx * 0.5;
+      const double rn = rp - dx;
+      d[uMN] -= dt * bm1 * (q0[qBN]) * 2.0 * rp / (rp * rp - rn * rn);
+      d[uMT1] -= dt * bm1 * (q0[qBT1]) * 2.0 * rp / (rp * rp - rn * rn);
+      d[uMT2] -= dt * bm1 * (q0[qBT2]) * 2.0 * rp / (rp * rp - rn * rn);
+      d[uERG] -= dt * bm1 * (uB) * 2.0 * rp / (rp * rp - rn * rn);
+      d[uBN] -= dt * bm1 * (q0[qVN]) * 2.0 * rp / (rp * rp - rn * rn);
+      d[uBT1] -= dt * bm1 * (q0[qVT1]) * 2.0 * rp / (rp * rp - rn * rn);
+      d[uBT2] -= dt * bm1 * (q0[qVT2]) * 2.0 * rp / (rp * rp - rn * rn);
+    }
+    if constexpr (EQ == EQGLM) {
+      const double sm1g = 0.5 * (q0[qSI] + sip);
+      d[uERG] -= dt * sm1g * (q0[qVN] * q0[qSI]) / dx;
+      d[uPSI] -= dt * sm1g * q0[qVN] / dx;
+    }
+  }
+  double u1[NV];
+  const double rp = R0 + dx * 0.5;
+  const double rn = rp - dx;
+#pragma unroll
+  for (int s = 0; s < NV; s++) u1[s] = 2.0 * (rn * Fm[s] - rp * Fp[s]) / (rp * rp - rn * rn);
+  const double Rc = cyl_Rcom(R0, dx);
+  if constexpr (!MHD) {
+    if (oa2) u1[uMN] += (q0[qPG] + (R0 - Rc) * s0[qPG]) / R0;
+    else u1[uMN] += q0[qPG] / R0;
+  }
+  else {
+    const double pm = (q0[qBN] * q0[qBN] + q0[qBT1] * q0[qBT1] + q0[qBT2] * q0[qBT2]) / 2.;
+    if (oa2) {
+      u1[uMN] += (q0[qPG] + pm +
+                  (R0 - Rc) * (s0[qPG] + q0[qBN] * s0[qBN] + q0[qBT1] * s0[qBT1] + q0[qBT2] * s0[qBT2])) /
+                 R0;
+      if constexpr (EQ == EQGLM) u1[uBN] += chyp * (q0[qSI] + (R0 - Rc) * s0[qSI]) / R0;
+    }
+    else {
+      u1[uMN] += (q0[qPG] + pm) / R0;
+      if constexpr (EQ == EQGLM) u1[uBN] += chyp * q0[qSI] / R0;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NV; s++) d[s] += dt * u1[s];
+}
+
 #ifndef PION_ROWS2_PF
 #define PION_ROWS2_PF 1
 #endif
@@ -106,7 +191,10 @@ PDEV void hslope3(const double *qm, const double *q0, const double *qp, const do
 #ifndef PION_ROWS2_MINWG
 #define PION_ROWS2_MINWG(EQ) 2
 #endif
-template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN, bool ZSL>
+// CYL: the 2-D instance for a cylindrical (z,R) grid (g.cyl == 1): the rows are marched along R, whose geometry enters
+// the slopes (differences of the cells' centres of mass), the edge states, the flux divergence and the source terms
+// exactly as in k_stage (VectorOps_Cyl, cyl_FV_solver_*); the z axis of the grid is the wavefront's x and stays Cartesian.
+template <int EQ, int NTR, int SOLVER, int OAMODE, bool PLAIN, bool ZSL, bool CYL = false>
 __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const StageArgs a)
 {
   typedef Eqn<EQ, NTR> E;
@@ -245,6 +333,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       const bool row_ok = (r < nrows_l);
       const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
       const unsigned off_r = (unsigned)c * 8u, offb_r = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
+      const int jy_r = j0 + (row_ok ? r : nrows_l - 1) + a.g.nbc[1];   // (CYL) all-cell y index of the lane's row
       // the row visited after this one (next row of the plane, or the first row of the next plane)
       const long cn = (r + 1 < nrows) ? crow0 + sy * ((r + 1 < nrows_l) ? r + 1 : nrows_l - 1) + sz * (k - (k0 - 1))
                                       : (noz ? c : crow0 + sz * (k + 1 - (k0 - 1)));   // (2-D: no next plane)
@@ -303,10 +392,15 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       // need no selects and no copies at a loop join (first-order instance -6 %, second-order -1 %).
       // (read-only scalars are captured by value, the per-task temporaries live inside: a `cond ? a : b` on two
       // by-reference captures becomes a select of their addresses, which pins both to scratch memory)
-      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz, u0](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
+      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz, u0, jy_r](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
         constexpr int TC = decltype(tc)::value;
         const int t = (TC < 0) ? t_run : TC;
         double eL[NV], eR[NV], f[NV], pstar[NV];
+        double s0y[NV];   // (CYL) this row's slope along R, sweep frame
+        if constexpr (CYL) {
+#pragma unroll
+          for (int v = 0; v < NV; v++) s0y[v] = 0.0;
+        }
         double bnm = 0.0, sim = 0.0, bnp = 0.0, sip = 0.0;   // B_n / psi of the lower and the upper neighbour cell
         long cl, st;
         int ax;
@@ -420,7 +514,42 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
               B[v] = F[v];
             }
           }
-          if (oa2) {
+          if constexpr (CYL) {
+            // (ysn carries the TRUE slope along R here; jA: all-cell y index of cell A)
+            if (oa2) {
+              const int jA = jy_r - (lower ? 1 : 0);
+              const double RA = cyl_R(a.g, jA), RB = cyl_R(a.g, jA + 1);
+              const double cA = cyl_Rcom(RA, dx), cB = cyl_Rcom(RB, dx);
+              double C[NV], sB[NV];
+              load_rot2<NV, MHD>(St, ncb, 1, shb + 2 * syb, off, C);
+              if (lower) {
+                double M[NV];
+                load_rot2<NV, MHD>(St, ncb, 1, -2 * syb, off, M);
+                cyl_slope3<NV>(M, A, B, cyl_Rcom(cyl_R(a.g, jA - 1), dx), cA, cB, true, ysn);
+              }
+              else {
+                // this row's slope, for the geometric source after the solve
+#pragma unroll
+                for (int v = 0; v < NV; v++) s0y[v] = ysn[v];
+              }
+              cyl_slope3<NV>(A, B, C, cA, cB, cyl_Rcom(cyl_R(a.g, jA + 2), dx), true, sB);
+#pragma unroll
+              for (int v = 0; v < NV; v++) {
+                // VectorOps_Cyl::SetEdgeState (VectorOps.cpp:1052-1092): distance of the face from the centre of mass
+                eL[v] = A[v] + ysn[v] * (RA + dx * 0.5 - cA);
+                eR[v] = B[v] + sB[v] * (RB - dx * 0.5 - cB);
+                ysn[v] = sB[v];
+              }
+            }
+            else {
+#pragma unroll
+              for (int v = 0; v < NV; v++) {
+                eL[v] = A[v];
+                eR[v] = B[v];
+              }
+            }
+          }
+          else if (oa2) {
             double C[NV], sB[NV];
             load_rot2<NV, MHD>(St, ncb, 1, shb + 2 * syb, off, C);
             if (lower) {
@@ -602,7 +731,10 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             double d[NV], yq0[NV];
             to_sweep<NV, MHD>(1, q0, yq0);
             to_sweep<NV, MHD>(1, dU, d);
-            apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
+            if constexpr (CYL)
+              apply_axis_cyl<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, s0y, dt, dx, cyl_R(a.g, jy_r - 1), cyl_R(a.g, jy_r), oa2,
+                                     a.fc.chyp);
+            else apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
             from_sweep<NV, MHD>(1, d, dU);
           }
 #pragma unroll
@@ -759,9 +891,39 @@ static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
   return (int)hipGetLastError();
 }
 
+// cylindrical (z,R) 2-D grids: the CYL instance (run-time spatial order, no LDS)
+template <int EQ, int NTR, int SOLVER>
+static int stage_rows2_go_cyl(const StageArgs &a0, hipStream_t s)
+{
+  StageArgs a = a0;
+  if (a.rows > 64) a.rows = 64;
+  if (a.rows < 1) a.rows = 1;
+  const int nzc = ((a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk) + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
+  const int nb4 = (rows_tiling(a).per_chunk + 3) / 4, nb8 = (nb4 + 7) / 8;
+  const long nblocks = 8L * nb8 * nzc;
+  // (the same specialisation rule as the Cartesian instances)
+  constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)
+                              || ((SOLVER == FLUX_RSroe || SOLVER == FLUX_FVS) && EQ == EQEUL);
+  if constexpr (specialise) {
+    const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
+                        && a.fc.artvisc != AV_HCORR_FKJ98);
+    if (plain && a.space_ooa == 2) {
+      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 2, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      return (int)hipGetLastError();
+    }
+    if (plain && a.space_ooa == 1) {
+      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 1, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+      return (int)hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 0, false, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
 template <int EQ, int NTR, int SOLVER>
 static int stage_rows2_go(const StageArgs &a, hipStream_t s)
 {
+  if (a.g.ndim == 2 && a.g.cyl == 1) return stage_rows2_go_cyl<EQ, NTR, SOLVER>(a, s);
   // a.zslope_lds: carry the z slope in LDS (fewer rows per wavefront) instead of rebuilding it
   if (a.zslope_lds && a.space_ooa == 2) return stage_rows2_go_z<EQ, NTR, SOLVER, true>(a, s);
   return stage_rows2_go_z<EQ, NTR, SOLVER, false>(a, s);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the round-3 profile evidence on the GPU box (run through gpurun from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of the bench command: M1 (default), M1 ideal MHD, M2, M3, the two 2-D
-#      workloads                                                                      -> gpurun_out/prof_r03_*/
+#      workloads and the two axisymmetric ones                                                                      -> gpurun_out/prof_r03_*/
 #   2. separate --pmc passes (each with --kernel-trace only; MI355X_MICROARCH.md: never mix --pmc with other trace
 #      domains; TCC block: 4 slots, FETCH_SIZE 3, WRITE_SIZE 2): FETCH_SIZE, WRITE_SIZE, the raw fabric-side read
 #      counters (requests, 32-B requests, DRAM-routed requests), L2 hit / miss, the SQ set, GRBM_GUI_ACTIVE
@@ -21,7 +21,9 @@ prof m2 --workload m2
 prof m3 --workload m3 --grid 256
 prof dmr2d --workload dmr2d --grid 4096
 prof mhd2d --workload mhd2d --grid 4096
-for wl in "m1" "m2 --workload m2" "m3 --workload m3 --grid 256" "dmr2d --workload dmr2d --grid 4096" "mhd2d --workload mhd2d --grid 4096"; do
+prof axi2d --workload axi2d --grid 4096
+prof mhdaxi2d --workload mhdaxi2d --grid 4096
+for wl in "m1" "m2 --workload m2" "m3 --workload m3 --grid 256" "dmr2d --workload dmr2d --grid 4096" "mhd2d --workload mhd2d --grid 4096" "axi2d --workload axi2d --grid 4096" "mhdaxi2d --workload mhdaxi2d --grid 4096"; do
   set -- $wl; w=$1; shift
   pmc ${w}_fetch "FETCH_SIZE" "$@"
   pmc ${w}_write "WRITE_SIZE" "$@"

@@ -11,6 +11,8 @@ python bench.py --workload m3 --grid 256 --no-cpu-baseline > $O/bench_m3.json 2>
 python bench.py --eqn mhd --no-cpu-baseline > $O/bench_mhd8.json 2>/dev/null
 python bench.py --workload dmr2d --grid 4096 --no-cpu-baseline > $O/bench_dmr2d.json 2>/dev/null
 python bench.py --workload mhd2d --grid 4096 --no-cpu-baseline > $O/bench_mhd2d.json 2>/dev/null
+python bench.py --workload axi2d --grid 4096 --no-cpu-baseline > $O/bench_axi2d.json 2>/dev/null
+python bench.py --workload mhdaxi2d --grid 4096 --no-cpu-baseline > $O/bench_mhdaxi2d.json 2>/dev/null
 for nz in 256 128 64; do
   python bench.py --nz $nz --no-cpu-baseline --no-parity-build > $O/slab_nz${nz}.json 2>/dev/null
   python bench.py --nz $nz --loopback --no-cpu-baseline --no-parity-build > $O/loop_nz${nz}.json 2>/dev/null

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 output of profiles/tools/collect_r03.sh (gpurun_out/) into the files kept under profiles/:
 
-  r03_<wl>_kernel_stats.csv     the --stats summaries (wl = m1, mhd8, m2, m3, dmr2d, mhd2d)
+  r03_<wl>_kernel_stats.csv     the --stats summaries (wl = m1, mhd8, m2, m3, dmr2d, mhd2d, axi2d, mhdaxi2d)
   r03_<wl>_under_rocprof.json   the JSON line bench.py printed in that profiled run
   r03_pmc_traffic.json          bytes per stage-kernel launch that left L2, per workload and per kernel instance:
                                 FETCH_SIZE / WRITE_SIZE from separate --pmc passes, KB -> bytes, read counter x the
@@ -25,7 +25,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
-WLS = ["m1", "mhd8", "m2", "m3", "dmr2d", "mhd2d"]
+WLS = ["m1", "mhd8", "m2", "m3", "dmr2d", "mhd2d", "axi2d", "mhdaxi2d"]
 KB = 1024.0   # FETCH_SIZE / WRITE_SIZE are reported in KB
 
 
@@ -129,7 +129,7 @@ def main():
                "note": "FETCH_SIZE counts requests that leave L2, Infinity-Cache hits included (MI355X_MICROARCH.md); read "
                        "bytes = FETCH_SIZE x 1024 x the aligned-stream correction (the stage-tiling correction is given "
                        "beside it: if the two differ, the truth for the stage kernels lies between)"}
-    for wl in ("m1", "m2", "m3", "dmr2d", "mhd2d"):
+    for wl in ("m1", "m2", "m3", "dmr2d", "mhd2d", "axi2d", "mhdaxi2d"):
         f, w = counters_per_kernel("pmc_r03_%s_fetch" % wl), counters_per_kernel("pmc_r03_%s_write" % wl)
         dur = durations(wl)
         inst = {}
@@ -169,7 +169,7 @@ def main():
     json.dump(l2, open(os.path.join(PROF, "r03_pmc_l2_fabric.json"), "w"), indent=1)
     # ---- SQ
     sq = {"kernel_source_hash": src, "workloads": {}}
-    for wl in ("m1", "m2", "m3", "dmr2d", "mhd2d"):
+    for wl in ("m1", "m2", "m3", "dmr2d", "mhd2d", "axi2d", "mhdaxi2d"):
         per = {k: {c: v[0] for c, v in cs.items()} for k, cs in counters_per_kernel("pmc_r03_%s_sq" % wl).items() if is_stage(k)}
         for k, c in per.items():
             wc = c.get("SQ_WAVE_CYCLES", 0.0)

@@ -177,3 +177,98 @@ def test_rows_kernel_equals_cell_kernel_on_large_grids(case, ng, monkeypatch):
         del P
     assert out[0][1] == out[1][1]
     assert np.array_equal(out[0][0], out[1][0])
+
+
+# ---- cylindrical (z,R) 2-D grids: the CYL instance of the rows kernel (geometry in slopes, edge states, divergence and
+# source terms along R) against the oracle and against the cell-per-thread kernel -------------------------------------
+def _cyl_case(kind, n, strict):
+    if kind == "hd_roe":
+        return problems.blast_axi2d(n, abi.EQEUL, abi.FLUX_RSroe, strict_fp=strict)
+    if kind == "hd_roe_tr_hcorr":
+        return problems.blast_axi2d(n, abi.EQEUL, abi.FLUX_RSroe, ntracer=1, artvisc=abi.AV_HCORR_FKJ98, strict_fp=strict)
+    if kind == "hd_fvs":
+        return problems.blast_axi2d(n, abi.EQEUL, abi.FLUX_FVS, strict_fp=strict)
+    if kind == "mhd_hlld":
+        return problems.blast_axi2d(n, abi.EQMHD, abi.FLUX_RS_HLLD, strict_fp=strict)
+    if kind == "glm_hlld_tr":
+        return problems.blast_axi2d(n, abi.EQGLM, abi.FLUX_RS_HLLD, ntracer=1, strict_fp=strict)
+    if kind == "glm_roe":
+        return problems.blast_axi2d(n, abi.EQGLM, abi.FLUX_RSroe, strict_fp=strict)
+    if kind == "glm_jet":
+        cfg, P, _ = problems.jet_axi2d(n, strict_fp=strict)
+        return cfg, P
+    raise KeyError(kind)
+
+
+CYL_CASES = ["hd_roe", "hd_roe_tr_hcorr", "hd_fvs", "mhd_hlld", "glm_hlld_tr", "glm_roe"]
+
+
+@pytest.mark.parametrize("n", [24, 140], ids=["24x12", "140x70"])
+@pytest.mark.parametrize("kind", CYL_CASES)
+def test_cyl_rows_kernel_strict_bitexact_vs_oracle(kind, n):
+    """one x tile and three (two full + remainder), 12 / 70 rows (not multiples of the 16 rows per wavefront)"""
+    cfg, P = _cyl_case(kind, n, 1)
+    run_pair(cfg, P, 3)
+
+
+@pytest.mark.parametrize("kind", CYL_CASES)
+def test_cyl_rows_kernel_fast_vs_oracle(kind):
+    cfg, P = _cyl_case(kind, 140, 0)
+    run_pair(cfg, P, 3, strict=False, tol=3e-11)
+
+
+@pytest.mark.parametrize("kind", ["hd_roe", "glm_hlld_tr"])
+@pytest.mark.parametrize("rows", ["1", "3", "20"])
+def test_cyl_rows_per_wavefront_and_cell_kernel_agree(kind, rows, monkeypatch):
+    out = []
+    for env in ({}, {"PION_ROWS": rows}, {"PION_ROWS_2D": "0"}):
+        for k in ("PION_ROWS", "PION_ROWS_2D"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg, P = _cyl_case(kind, 76, 1)
+        with _gpu(cfg) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            sc.time_int(3)
+            out.append((g.download(0), sc.simtime))
+    for A, t in out[1:]:
+        assert t == out[0][1]
+        assert np.array_equal(A, out[0][0])
+
+
+@pytest.mark.parametrize("kind", ["glm_hlld_tr", "hd_roe"])
+def test_cyl_rows_kernel_equals_cell_kernel_on_a_large_grid(kind, monkeypatch):
+    """2048 x 1024 axisymmetric grid: thousands of tiles, every XCD's share, the fused time-step reduction"""
+    out = []
+    for env in ({}, {"PION_STAGE_KERNEL": "cell", "PION_ROWS_2D": "0"}):
+        for k in ("PION_STAGE_KERNEL", "PION_ROWS_2D"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg, P = _cyl_case(kind, 2048, 1)
+        with _gpu(cfg) as g:
+            sc = driver.SimControl(g, cfg)
+            sc.init(P)
+            dts = []
+            for _ in range(3):
+                dts.append(sc.calculate_timestep())
+                sc.advance_time()
+            out.append((g.download(0), dts))
+        del P
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0])
+
+
+def test_cyl_jet_with_internal_boundary_strict_vs_oracle():
+    cfg, P, (radius, state) = problems.jet_axi2d(96, strict_fp=1)
+    res = []
+    for mk in (lambda: _cpu(cfg), lambda: _gpu(cfg)):
+        with mk() as s:
+            s.set_jet(radius, state)
+            sc = driver.SimControl(s, cfg)
+            sc.init(P)
+            sc.time_int(4)
+            res.append((s.download(0), sc.simtime))
+    assert res[0][1] == res[1][1]
+    assert np.array_equal(res[0][0], res[1][0])
