@@ -193,6 +193,10 @@ def parity_build_run(args, cfg, device, dt_lim, steps=3, warmup=1):
             _, P = problems.double_mach_reflection(args.n, strict_fp=1)
         elif args.workload == "mhd2d":
             P = problems.fill_mhd_blastwave(cfg)
+        elif args.workload == "axi2d":
+            _, P = problems.blast_axi2d(args.n, abi.EQEUL, abi.FLUX_RSroe, strict_fp=1)
+        elif args.workload == "mhdaxi2d":
+            _, P = problems.blast_axi2d(args.n, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
         else:
             from pion_amd import cooling
             P, (widx, wst), dt_lim = problems.fill_wind3d(cfg, args.n)
