@@ -104,9 +104,52 @@ PDEV void cyl_slope3(const double *qm, const double *q0, const double *qp, const
 template <int EQ, int NV>
 PDEV void apply_axis_cyl(double *d, const double *q0, const double bnm, const double sim, const double bnp, const double sip,
                          const double *Fm, const double *Fp, const double *s0, const double dt, const double dx,
-                         const double Rm1, const double R0, const bool oa2, const double chyp)
+                         const double Rm1, const double R0, const double Rc, const bool oa2, const double chyp)
 {
   constexpr bool MHD = (EQ != EQEUL);
+#ifdef PION_FAST_MATH
+  // fast build: the same sums regrouped -- one factor per face for the Powell source (its state factor is shared by
+  // the two faces), one per face for the R-weighted divergence (exact in real arithmetic, differs by rounding)
+  {
+    const double rn = R0 - dx * 0.5, rp = R0 + dx * 0.5;
+    const double idn = 2.0 * dt / (rp * rp - rn * rn);
+    const double wn = idn * rn, wp = idn * rp;
+    if constexpr (MHD) {
+      const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
+      const double kb = wn * (0.5 * (bnm + q0[qBN])) - wp * (0.5 * (q0[qBN] + bnp));
+      d[uMN] += kb * q0[qBN];
+      d[uMT1] += kb * q0[qBT1];
+      d[uMT2] += kb * q0[qBT2];
+      d[uERG] += kb * uB;
+      d[uBN] += kb * q0[qVN];
+      d[uBT1] += kb * q0[qVT1];
+      d[uBT2] += kb * q0[qVT2];
+      if constexpr (EQ == EQGLM) {
+        const double ks = (dt / dx) * (0.5 * (sim - sip)) * q0[qVN];
+        d[uERG] += ks * q0[qSI];
+        d[uPSI] += ks;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NV; s++) d[s] += wn * Fm[s] - wp * Fp[s];
+    const double iR0 = dt / R0;
+    if constexpr (!MHD) {
+      d[uMN] += iR0 * (oa2 ? (q0[qPG] + (R0 - Rc) * s0[qPG]) : q0[qPG]);
+    }
+    else {
+      const double pm = (q0[qBN] * q0[qBN] + q0[qBT1] * q0[qBT1] + q0[qBT2] * q0[qBT2]) * 0.5;
+      if (oa2) {
+        d[uMN] += iR0 * (q0[qPG] + pm + (R0 - Rc) * (s0[qPG] + q0[qBN] * s0[qBN] + q0[qBT1] * s0[qBT1] + q0[qBT2] * s0[qBT2]));
+        if constexpr (EQ == EQGLM) d[uBN] += iR0 * chyp * (q0[qSI] + (R0 - Rc) * s0[qSI]);
+      }
+      else {
+        d[uMN] += iR0 * (q0[qPG] + pm);
+        if constexpr (EQ == EQGLM) d[uBN] += iR0 * chyp * q0[qSI];
+      }
+    }
+    return;
+  }
+#endif
   if constexpr (MHD) {
     const double uB = q0[qBN] * q0[qVN] + q0[qBT1] * q0[qVT1] + q0[qBT2] * q0[qVT2];
     const double bm0 = 0.5 * (bnm + q0[qBN]);
@@ -150,7 +193,6 @@ PDEV void apply_axis_cyl(double *d, const double *q0, const double bnm, const do
   const double rn = rp - dx;
 #pragma unroll
   for (int s = 0; s < NV; s++) u1[s] = 2.0 * (rn * Fm[s] - rp * Fp[s]) / (rp * rp - rn * rn);
-  const double Rc = cyl_Rcom(R0, dx);
   if constexpr (!MHD) {
     if (oa2) u1[uMN] += (q0[qPG] + (R0 - Rc) * s0[qPG]) / R0;
     else u1[uMN] += q0[qPG] / R0;
@@ -327,6 +369,8 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
     double Fy[NV], ysn[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) Fy[v] = ysn[v] = 0.0;
+    // (CYL) centres of mass of rows j-1 .. j+2, carried from row to row: one R_com (a division) per row instead of four
+    double cyc[4] = {0.0, 0.0, 0.0, 0.0};
 
 #pragma unroll 1
     for (int r = 0; r < nrows; r++) {
@@ -334,6 +378,20 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       const long c = crow0 + sy * (row_ok ? r : nrows_l - 1) + sz * (k - (k0 - 1));
       const unsigned off_r = (unsigned)c * 8u, offb_r = (unsigned)c;   // the lane's cell: byte offsets of doubles / flags
       const int jy_r = j0 + (row_ok ? r : nrows_l - 1) + a.g.nbc[1];   // (CYL) all-cell y index of the lane's row
+      if constexpr (CYL) {
+        if (r == 0 || !row_ok) {
+          cyc[0] = cyl_Rcom(cyl_R(a.g, jy_r - 1), dx);
+          cyc[1] = cyl_Rcom(cyl_R(a.g, jy_r), dx);
+          cyc[2] = cyl_Rcom(cyl_R(a.g, jy_r + 1), dx);
+        }
+        else {
+          cyc[0] = cyc[1];
+          cyc[1] = cyc[2];
+          cyc[2] = cyc[3];
+        }
+        cyc[3] = cyl_Rcom(cyl_R(a.g, jy_r + 2), dx);
+      }
+      const double cy_m1 = cyc[0], cy_0 = cyc[1], cy_p1 = cyc[2], cy_p2 = cyc[3];   // (by value into the task)
       // the row visited after this one (next row of the plane, or the first row of the next plane)
       const long cn = (r + 1 < nrows) ? crow0 + sy * ((r + 1 < nrows_l) ? r + 1 : nrows_l - 1) + sz * (k - (k0 - 1))
                                       : (noz ? c : crow0 + sz * (k + 1 - (k0 - 1)));   // (2-D: no next plane)
@@ -392,7 +450,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
       // need no selects and no copies at a loop join (first-order instance -6 %, second-order -1 %).
       // (read-only scalars are captured by value, the per-task temporaries live inside: a `cond ? a : b` on two
       // by-reference captures becomes a select of their addresses, which pins both to scratch memory)
-      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz, u0, jy_r](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
+      auto task = [&, c, off_r, offb_r, doff_n, doffb_n, r, row_ok, prime, k, noz, u0, jy_r, cy_m1, cy_0, cy_p1, cy_p2](auto tc, const int t_run, const bool lower) __attribute__((always_inline)) {
         constexpr int TC = decltype(tc)::value;
         const int t = (TC < 0) ? t_run : TC;
         double eL[NV], eR[NV], f[NV], pstar[NV];
@@ -519,7 +577,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             if (oa2) {
               const int jA = jy_r - (lower ? 1 : 0);
               const double RA = cyl_R(a.g, jA), RB = cyl_R(a.g, jA + 1);
-              const double cA = cyl_Rcom(RA, dx), cB = cyl_Rcom(RB, dx);
+              const double cA = lower ? cy_m1 : cy_0, cB = lower ? cy_0 : cy_p1, cC = lower ? cy_p1 : cy_p2;
               double C[NV], sB[NV];
               load_rot2<NV, MHD>(St, ncb, 1, shb + 2 * syb, off, C);
               if (lower) {
@@ -532,7 +590,7 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
 #pragma unroll
                 for (int v = 0; v < NV; v++) s0y[v] = ysn[v];
               }
-              cyl_slope3<NV>(A, B, C, cA, cB, cyl_Rcom(cyl_R(a.g, jA + 2), dx), true, sB);
+              cyl_slope3<NV>(A, B, C, cA, cB, cC, true, sB);
 #pragma unroll
               for (int v = 0; v < NV; v++) {
                 // VectorOps_Cyl::SetEdgeState (VectorOps.cpp:1052-1092): distance of the face from the centre of mass
@@ -732,8 +790,8 @@ __global__ __launch_bounds__(256, PION_ROWS2_MINWG(EQ)) void k_stage_rows2(const
             to_sweep<NV, MHD>(1, q0, yq0);
             to_sweep<NV, MHD>(1, dU, d);
             if constexpr (CYL)
-              apply_axis_cyl<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, s0y, dt, dx, cyl_R(a.g, jy_r - 1), cyl_R(a.g, jy_r), oa2,
-                                     a.fc.chyp);
+              apply_axis_cyl<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, s0y, dt, dx, cyl_R(a.g, jy_r - 1), cyl_R(a.g, jy_r), cy_0,
+                                     oa2, a.fc.chyp);
             else apply_axis<EQ, NV>(d, yq0, bnm, sim, bnp, sip, Fy, f, dt, dx);
             from_sweep<NV, MHD>(1, d, dU);
           }
