@@ -89,6 +89,8 @@ struct StageArgs {
   // tail is), nzb of them
   int nzb, zcmax;
   int rows;           // y-rows per wavefront in k_stage_rows2
+  int rows_auto;      // 2-D: the launcher may pick the rows per wavefront for the instance it launches (its occupancy)
+  int ncu;            // compute units of the device (for that choice)
   int kz0, kz1;       // on-grid z planes [kz0,kz1) this launch updates (k_stage_rows2; k_stage: whole grid)
   int kz2, kz3;       // and a second strip [kz2,kz3) (empty when kz3 <= kz2): the two z-boundary strips
   unsigned long long *dtres;  // k_stage_rows2, full step: min t_dyn / t_mp bits of the new state (or null)

@@ -1413,6 +1413,8 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
   // periodic x: k_stage_rows2 writes the x ghost images of its rows (the boundary launch then skips them)
   a.xwrap = (a.use_march != 0 && h->fuse_bc && cfg.bc_type[0] == PION_BC_PERIODIC
              && cfg.bc_type[1] == PION_BC_PERIODIC && h->g.ng[0] >= 2 * h->g.nbc[0]) ? 1 : 0;
+  a.rows_auto = 0;
+  a.ncu = h->ncu;
   if (a.use_march != 0 && h->g.ndim == 2) {
     // 2-D: rows per wavefront marched along y (nothing in LDS): 2 + 1/R solves per cell against the number of
     // wavefronts (measured, 4096 x 1260 Euler Roe-CV / 4096 x 6144 GLM-MHD HLLD, Mcell-updates/s: R = 4 7694 / 5940,
@@ -1425,6 +1427,9 @@ static int stage_launch(Handle *h, double dt_stage, int space_ooa, int is_full_s
     }
     a.rows = (h->rows > 0) ? h->rows : r2;
     if (a.rows > 64) a.rows = 64;
+    // (without PION_ROWS the launcher refines the choice for the instance it launches: its occupancy decides how
+    // many wavefronts a "round" holds, stage_rows2.h rows2_pick_rows_2d)
+    a.rows_auto = (h->rows > 0) ? 0 : 1;
   }
   else if (a.use_march != 0)
     a.rows = cfg.strict_fp ? fp_strict::stage_rows2_rows(cfg.eqntype, cfg.ntracer, a.zslope_lds && space_ooa == 2, space_ooa == 2 ? h->rows : h->rows1)

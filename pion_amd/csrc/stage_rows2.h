@@ -911,21 +911,66 @@ __host__ inline int rows2_rmax()
   return r > 8 ? 8 : r;
 }
 
-template <int EQ, int NTR, int SOLVER, bool ZSL>
-static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
+// 2-D launches: rows per wavefront for THIS instance.  A 2-D launch is one to a few "rounds" of wavefronts (one
+// wavefront marches its R rows from start to end), so what matters is how well the wavefronts fill the slots of the
+// rounds they need: R is the value in [8, 64] with the best (filled share of the slots) / (2 + 1/R Riemann solves per
+// cell) -- for launches of at most three rounds at the caller's R; the slots follow from the occupancy of the instance
+// (its registers).  Measured, Euler Roe-CV 4096 x 1260
+// (66 x-tiles, 3 wavefronts per SIMD): R = 16 (1.7 rounds) 12 790, 28 (0.97 of one round) 14 240-14 300, 32 13 150
+// Mcell-updates/s.  The result does not depend on R (tests/test_gpu_xtile.py).
+template <void (*KERNEL)(const StageArgs)>
+static int rows2_pick_rows_2d(const StageArgs &a)
 {
-  constexpr int NV = Eqn<EQ, NTR>::NV;
-  constexpr int NZ = ZSL ? 2 * NV : NV;
-  StageArgs a = a0;
+  static int wg_per_cu = 0;   // (per instance)
+  if (wg_per_cu == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERNEL, 256, 0) != hipSuccess || n < 1) n = 2;
+    wg_per_cu = n;
+  }
+  const long slots = 4L * wg_per_cu * (a.ncu > 0 ? a.ncu : 256);
+  int best = a.rows;
+  double best_score = -1.0;
+  StageArgs t = a;
+  // (a launch of many rounds is filled well enough at the caller's rows, and long columns cost it L2 locality:
+  // 4096 x 6144 GLM-MHD HLLD, 12.4 rounds at R = 16: 8340 Mcell-updates/s, R = 50 -- one round fewer -- 7350)
+  if ((rows_tiling(a).per_chunk + slots - 1) / slots > 3) return a.rows;
+  for (int R = 8; R <= 64; R++) {
+    t.rows = R;
+    const long waves = rows_tiling(t).per_chunk;
+    const long rounds = (waves + slots - 1) / slots;
+    const double score = ((double)waves / (double)(rounds * slots)) / (2.0 + 1.0 / R);
+    if (score > best_score * 1.0000001) {
+      best_score = score;
+      best = R;
+    }
+  }
+  return best;
+}
+// one launch of an instance: rows per wavefront (2-D: picked here when the caller leaves the choice), grid, LDS
+template <void (*KERNEL)(const StageArgs)>
+static int rows2_launch(StageArgs a, const int rmax, const size_t lds_bytes_per_row, hipStream_t s)
+{
   const bool noz = (a.g.ndim == 2);
-  const int rmax = noz ? 64 : rows2_rmax<NV, ZSL>();   // (2-D: nothing is carried in LDS)
+  if (noz && a.rows_auto) a.rows = rows2_pick_rows_2d<KERNEL>(a);
   if (a.rows > rmax) a.rows = rmax;
   if (a.rows < 1) a.rows = 1;
-  const int R = a.rows;
   const int nzc = ((a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk) + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
   const int nb4 = (rows_tiling(a).per_chunk + 3) / 4, nb8 = (nb4 + 7) / 8;
   const long nblocks = 8L * nb8 * nzc;   // (see the kernel: an eighth of the x-y tiles per XCD, through all chunks)
-  const size_t shmem = noz ? 0 : sizeof(double) * 4 * R * NZ * 64;
+  const size_t shmem = noz ? 0 : lds_bytes_per_row * a.rows;
+  hipLaunchKernelGGL(KERNEL, dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+  return (int)hipGetLastError();
+}
+
+template <int EQ, int NTR, int SOLVER, bool ZSL>
+static int stage_rows2_go_z(const StageArgs &a, hipStream_t s)
+{
+  constexpr int NV = Eqn<EQ, NTR>::NV;
+  constexpr int NZ = ZSL ? 2 * NV : NV;
+  const bool noz = (a.g.ndim == 2);
+  const int rmax = noz ? 64 : rows2_rmax<NV, ZSL>();   // (2-D: nothing is carried in LDS)
+  constexpr size_t lds_row = sizeof(double) * 4 * NZ * 64, lds_row1 = sizeof(double) * 4 * NV * 64;
+  const int rmax1 = noz ? 64 : rows2_rmax<NV, false>();
   // compile-time spatial order and "no H-correction / microphysics" for the production instances
   // (MHD HLLD, Euler Roe-CV, Euler FVS), run-time for the others
   constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)
@@ -934,48 +979,29 @@ static int stage_rows2_go_z(const StageArgs &a0, hipStream_t s)
     const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
                         && a.fc.artvisc != AV_HCORR_FKJ98);
     if (plain) {
-      if (a.space_ooa == 2)
-        hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 2, true, ZSL>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-      else
-        hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 1, true, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+      if (a.space_ooa == 2) return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 2, true, ZSL>>(a, rmax, lds_row, s);
+      return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 1, true, false>>(a, rmax1, lds_row1, s);
     }
-    else if (a.space_ooa == 2)
-      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 2, false, ZSL>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-    else
-      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 1, false, false>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+    if (a.space_ooa == 2) return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 2, false, ZSL>>(a, rmax, lds_row, s);
+    return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 1, false, false>>(a, rmax1, lds_row1, s);
   }
   else
-    hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 0, false, ZSL>), dim3((unsigned)nblocks), dim3(256), shmem, s, a);
-  return (int)hipGetLastError();
+    return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 0, false, ZSL>>(a, rmax, lds_row, s);
 }
 
-// cylindrical (z,R) 2-D grids: the CYL instance (run-time spatial order, no LDS)
+// cylindrical (z,R) 2-D grids: the CYL instances (the same specialisation rule, no LDS)
 template <int EQ, int NTR, int SOLVER>
-static int stage_rows2_go_cyl(const StageArgs &a0, hipStream_t s)
+static int stage_rows2_go_cyl(const StageArgs &a, hipStream_t s)
 {
-  StageArgs a = a0;
-  if (a.rows > 64) a.rows = 64;
-  if (a.rows < 1) a.rows = 1;
-  const int nzc = ((a.nzb > 0) ? a.nzb : (a.kz1 - a.kz0 + a.zchunk - 1) / a.zchunk) + (a.kz3 - a.kz2 + a.zchunk - 1) / a.zchunk;
-  const int nb4 = (rows_tiling(a).per_chunk + 3) / 4, nb8 = (nb4 + 7) / 8;
-  const long nblocks = 8L * nb8 * nzc;
-  // (the same specialisation rule as the Cartesian instances)
   constexpr bool specialise = (SOLVER == FLUX_RS_HLLD && EQ != EQEUL)
                               || ((SOLVER == FLUX_RSroe || SOLVER == FLUX_FVS) && EQ == EQEUL);
   if constexpr (specialise) {
     const bool plain = (a.cooling == 0 && !a.fc.mp.present && a.fc.artvisc != AV_HCORRECTION
                         && a.fc.artvisc != AV_HCORR_FKJ98);
-    if (plain && a.space_ooa == 2) {
-      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 2, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
-      return (int)hipGetLastError();
-    }
-    if (plain && a.space_ooa == 1) {
-      hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 1, true, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
-      return (int)hipGetLastError();
-    }
+    if (plain && a.space_ooa == 2) return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 2, true, false, true>>(a, 64, 0, s);
+    if (plain && a.space_ooa == 1) return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 1, true, false, true>>(a, 64, 0, s);
   }
-  hipLaunchKernelGGL((k_stage_rows2<EQ, NTR, SOLVER, 0, false, false, true>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
-  return (int)hipGetLastError();
+  return rows2_launch<k_stage_rows2<EQ, NTR, SOLVER, 0, false, false, true>>(a, 64, 0, s);
 }
 
 template <int EQ, int NTR, int SOLVER>
