@@ -19,15 +19,18 @@ BRIDGE = os.path.join(ROOT, "oracle", "_ref", "libpion_ref_bridge.so")
 
 
 @pytest.mark.skipif(not (have_ref() and os.path.exists(BRIDGE)), reason="oracle/_ref not built (needs /root/reference)")
-@pytest.mark.parametrize("case", ["glm_hlld_3d", "hd_roe_3d_bcs", "dmr_2d", "hd_jet_3d", "cool_fvs_3d"])
+@pytest.mark.parametrize("case", ["glm_hlld_3d", "hd_roe_3d_bcs", "dmr_2d", "hd_jet_3d", "cool_fvs_3d", "cyl_glm_hlld", "cyl_glm_jet",
+                                  "cyl_hd_hcorr_tr"])
 def test_bridge_drives_the_reference_grid(case):
     abi.share_torch_hip_runtime()
     if case == "glm_hlld_3d":
         cfg, P = problems.mhd_blast_generic([20, 12, 10], abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1)
     elif case == "hd_roe_3d_bcs":
         cfg, P = problems.hd_blast_box([16, 14, 12], solver=abi.FLUX_RSroe, ntracer=1, strict_fp=1)
-    elif case == "hd_jet_3d":
-        # internal JETBC boundary: the bridge hands JP.jetradius / JP.jetstate to pion_gpu_set_jet
+    elif case in ("hd_jet_3d", "cyl_glm_hlld", "cyl_glm_jet", "cyl_hd_hcorr_tr"):
+        # internal JETBC boundary: the bridge hands JP.jetradius / JP.jetstate to pion_gpu_set_jet; the cyl_* cases are
+        # cylindrical (z,R) grids (axisymmetric boundary on the axis): the reference's cell lists driven through the
+        # CYL instance of the rows kernel
         cfg, P = gc.step_case(case)
     elif case == "cool_fvs_3d":
         # EP.cooling = 8 with the reference's own mp_only_cooling as MP: the bridge builds and hands over the tables
