@@ -23,8 +23,11 @@ def test_cpp_time_int_equals_python_driver():
     host.pion_host_sim_download.argtypes = [C.c_void_p, C.c_int, dp]
     host.pion_host_sim_destroy.argtypes = [C.c_void_p]
     host.pion_host_sim_destroy.restype = None
+    # (3-D periodic GLM-MHD, 3-D Euler with physical faces, and two 2-D grids: Cartesian and cylindrical (z,R))
     for cfg, P in (problems.mhd_blastwave(20, 3, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1),
-                   problems.hd_blast_octant(20, 3, solver=abi.FLUX_RSroe, strict_fp=1, nzones=3.0)):
+                   problems.hd_blast_octant(20, 3, solver=abi.FLUX_RSroe, strict_fp=1, nzones=3.0),
+                   problems.mhd_blastwave(40, 2, abi.EQGLM, abi.FLUX_RS_HLLD, strict_fp=1),
+                   problems.blast_axi2d(72, abi.EQGLM, abi.FLUX_RS_HLLD, ntracer=1, strict_fp=1)):
         s = C.c_void_p()
         assert host.pion_host_sim_create(C.byref(cfg), 0, C.byref(s)) == 0
         Pc = np.ascontiguousarray(P).reshape(-1)
