@@ -39,26 +39,24 @@ PDEV double ldu_once(const char *ubase, const unsigned off)""")
 rep("  bool pf_valid = false;",
     "  unsigned long long tw[3] = {0,0,0}, tcmp[3] = {0,0,0}, tup = 0, tk0 = stamp(false);\n  bool pf_valid = false;")
 rep("        constexpr int TC = decltype(tc)::value;\n",
-    "        constexpr int TC = decltype(tc)::value;\n        const unsigned long long sA = stamp(false);\n        unsigned long long sB = sA;\n")
+    "        constexpr int TC = decltype(tc)::value;\n        const unsigned long long tsA = stamp(false);\n        unsigned long long tsB = tsA;\n")
 rep("""              qp[v] = ldu(St + v * ncb + 8, off);
             }
 """, """              qp[v] = ldu(St + v * ncb + 8, off);
             }
-            sB = stamp(true);
+            tsB = stamp(true);
 """)
-rep("            hslope3<NV>(A, B, C, dx, thr, sB);", "            sB = stamp(true);\n            hslope3<NV>(A, B, C, dx, thr, sB_);")
-rep("double C[NV], sB[NV];", "double C[NV], sB_[NV];")
-rep("eR[v] = B[v] - sB[v] * 0.5;", "eR[v] = B[v] - sB_[v] * 0.5;")
-rep("ysn[v] = sB[v];", "ysn[v] = sB_[v];")
-rep("            hslope3<NV>(zq0, qp1, qp2, dx, thr, sn);", "            sB = stamp(true);\n            hslope3<NV>(zq0, qp1, qp2, dx, thr, sn);")
+rep("            hslope3<NV>(A, B, C, dx, thr, sB);", "            tsB = stamp(true);\n            hslope3<NV>(A, B, C, dx, thr, sB);")
+rep("              cyl_slope3<NV>(A, B, C, cA, cB, cC, true, sB);", "              tsB = stamp(true);\n              cyl_slope3<NV>(A, B, C, cA, cB, cC, true, sB);")
+rep("            hslope3<NV>(zq0, qp1, qp2, dx, thr, sn);", "            tsB = stamp(true);\n            hslope3<NV>(zq0, qp1, qp2, dx, thr, sn);")
 rep("""          for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = f[v];
         }
       };""", """          for (int v = 0; v < NV; v++) ZS2(r, NZ - NV + v) = f[v];
         }
-        const unsigned long long sC = stamp(false);
+        const unsigned long long tsC = stamp(false);
         const int ti = (t == 0) ? 0 : (t == 2 ? 1 : 2);
-        tw[ti] += sB - sA;
-        tcmp[ti] += sC - sB;
+        tw[ti] += tsB - tsA;
+        tcmp[ti] += tsC - tsB;
       };""")
 rep("      if (!prime && writer && row_ok) {\n        const unsigned off = pin_v(off_r), offb = pin_v(offb_r);",
     "      const unsigned long long sU = stamp(false);\n      if (!prime && writer && row_ok) {\n        const unsigned off = pin_v(off_r), offb = pin_v(offb_r);")
@@ -90,8 +88,9 @@ rep("""            tmp = (t < tmp) ? t : tmp;
     }
   }
 """)
-rep("  return (int)hipGetLastError();\n}\n\ntemplate <int EQ, int NTR, int SOLVER>\nstatic int stage_rows2_go(",
-    """  if (getenv("PION_DBG")) {
+rep("  hipLaunchKernelGGL(KERNEL, dim3((unsigned)nblocks), dim3(256), shmem, s, a);\n  return (int)hipGetLastError();",
+    """  hipLaunchKernelGGL(KERNEL, dim3((unsigned)nblocks), dim3(256), shmem, s, a);
+  if (getenv("PION_DBG")) {
     hipStreamSynchronize(s);
     unsigned long long h[32];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbgt), sizeof(h));
@@ -103,6 +102,6 @@ rep("  return (int)hipGetLastError();\n}\n\ntemplate <int EQ, int NTR, int SOLVE
     unsigned long long z[32] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_dbgt), z, sizeof(z));
   }
-""" + "  return (int)hipGetLastError();\n}\n\ntemplate <int EQ, int NTR, int SOLVER>\nstatic int stage_rows2_go(")
+  return (int)hipGetLastError();""")
 open(p, "w").write(s)
 print("instrumented copy in", dst)
